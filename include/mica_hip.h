@@ -1,0 +1,122 @@
+/*
+ * mica_hip.h - C ABI of the MI355X-native MICA voxel-grid hot path (libmica_hip.so).
+ *
+ * Drop-in boundary for:  tile (reference utils/create_grids.py:124-176)
+ *                     -> network forward (reference models/model.py:331-348)
+ *                     -> softmax/argmax heads (reference utils/predict.py:342-349)
+ *                     -> stitch (reference utils/predict.py:459-501)
+ *                     -> map normalisation statistics (reference utils/preprocessing.py:122-133)
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, integer return codes (0 = ok, <0 = error); after an error
+ *     mica_last_error(ctx) returns a static/ctx-owned description.  No exceptions cross the ABI.
+ *   - every pointer named d_* is DEVICE memory owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); h_* is HOST memory.  `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - one mica_ctx per GPU; a ctx is not thread-safe, different ctxs are independent.
+ *   - all calls are asynchronous on `stream` unless stated otherwise.
+ *   - volumes are C-contiguous [N0][N1][N2] in the (x,y,z) index order the reference uses after
+ *     GridCreator.transpose (create_grids.py:67-87); tiles are [W][W][W], W = grid + 2*pad.
+ */
+#ifndef MICA_HIP_H
+#define MICA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mica_ctx mica_ctx;
+
+#define MICA_OK 0
+#define MICA_ERR_ARG -1
+#define MICA_ERR_HIP -2
+#define MICA_ERR_STATE -3
+#define MICA_ERR_RANGE -4   /* an activation left the range the split-f16 MFMA path represents */
+
+/* AF3-feature gating of MultiScaleInput.forward (model.py:56-63). */
+#define MICA_AF_NONE 0      /* af_features is None                                  (model.py:56)  */
+#define MICA_AF_PER_TILE 1  /* |af|.sum() < 1e-6 tested per tile = reference at batch 1 (predict.py:193,279) */
+#define MICA_AF_BATCH 2     /* tested over the whole batch, as MICA.forward does     (model.py:60)  */
+
+int mica_abi_version(void);
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* Allocates the activation workspace for up to max_batch tiles of tile_size^3 voxels in flight. */
+int mica_create(int device, int max_batch, int tile_size, mica_ctx** out);
+void mica_destroy(mica_ctx* ctx);
+const char* mica_last_error(const mica_ctx* ctx);   /* ctx may be NULL: last create() error */
+int64_t mica_workspace_bytes(const mica_ctx* ctx);
+
+/* ---- weights: replaces CryoEMPredictor.load_model (predict.py:217-258) ------------------ */
+/* One call per state_dict tensor (125 of them, names without the "module." prefix, fp32,
+ * torch layout: Conv3d [Cout][Cin/groups][kD][kH][kW], Linear [out][in], fpn.weights [3]).   */
+int mica_load_weight(mica_ctx* ctx, const char* name, const float* h_data, const int64_t* shape, int ndim);
+/* Checks that all 125 tensors are present with the right shapes, uploads and packs them into the
+ * kernels' layouts (split-f16 [cin/16][tap][hi|lo][k-half][Cout][8]); blocks until done.      */
+int mica_finalize_weights(mica_ctx* ctx);
+
+/* ---- inner boundary: MICA.forward (model.py:331-348) ------------------------------------ */
+/* d_map f32[B][1][S^3], d_af f32[B][24][S^3] or NULL (NCDHW, S = tile_size)
+ * -> logits d_bb f32[B][4][S^3], d_ca f32[B][4][S^3], d_aa f32[B][21][S^3] (NCDHW).           */
+int mica_forward_logits(mica_ctx* ctx, const float* d_map, const float* d_af, int batch, int af_mode,
+                        float* d_bb, float* d_ca, float* d_aa, void* stream);
+
+/* ---- forward + head post-processing: run_inference's loop body (predict.py:336-363) ------ */
+/* -> d_bb_prob f32[B][S^3], d_ca_prob f32[B][S^3], d_aa_prob f32[B][20][S^3],
+ *    d_aa_pred f32[B][S^3] holding 0..19 (the reference stitches it into a float32 volume,
+ *    predict.py:462).                                                                         */
+int mica_forward_tiles(mica_ctx* ctx, const float* d_map, const float* d_af, int batch, int af_mode,
+                       float* d_bb_prob, float* d_ca_prob, float* d_aa_prob, float* d_aa_pred, void* stream);
+/* Post-processing alone (predict.py:342-349) on NCDHW logits. */
+int mica_postprocess(mica_ctx* ctx, const float* d_bb, const float* d_ca, const float* d_aa, int batch,
+                     float* d_bb_prob, float* d_ca_prob, float* d_aa_prob, float* d_aa_pred, void* stream);
+
+/* ---- tiler: GridCreator.create_grids_from_mrc (create_grids.py:124-176), disk-free ------- */
+/* Host, pure integer: number of tiles = prod(ceil(N/grid)); table int64[T][6] = (i,j,k,di,dj,dk)
+ * in the reference's lexicographic loop order (create_grids.py:143-149).  Returns T or <0.    */
+int64_t mica_tile_count(int64_t n0, int64_t n1, int64_t n2, int grid);
+int64_t mica_tile_table(int64_t n0, int64_t n1, int64_t n2, int grid, int64_t* h_table, int64_t capacity);
+/* Device gather: d_vol f32[C][N0][N1][N2] -> d_tiles f32[count][C][W^3] for tiles
+ * first..first+count-1 of the table (zero padded exactly like np.pad, create_grids.py:135-139). */
+int mica_gather_tiles(mica_ctx* ctx, const float* d_vol, int channels, int64_t n0, int64_t n1, int64_t n2,
+                      int grid, int pad, int64_t first, int64_t count, float* d_tiles, void* stream);
+
+/* ---- stitch: reconstruct_volume (predict.py:459-501) ------------------------------------- */
+/* d_tiles f32[count][C][W^3] (tiles first.. of the table) -> central grid^3 regions scattered into
+ * d_vol f32[C][N0][N1][N2].  The caller zero-initialises d_vol (predict.py:459-462).           */
+int mica_stitch_tiles(mica_ctx* ctx, const float* d_tiles, int channels, int64_t n0, int64_t n1, int64_t n2,
+                      int grid, int pad, int64_t first, int64_t count, float* d_vol, void* stream);
+
+/* ---- normaliser: preprocessing.py:122-133 (zoom factor 1 path) ---------------------------- */
+/* In place on d_vol f32[n]: nan_to_num, subtract median / zero below it, clip at the 99.9th
+ * percentile of the positives (numpy 'linear' interpolation) and divide.  Synchronous.
+ * h_stats[0] = median, h_stats[1] = percentile.  Returns MICA_ERR_STATE where the reference
+ * reports "No positive values" / "Percentile value is zero" (preprocessing.py:159-165).      */
+int mica_normalise_map(mica_ctx* ctx, float* d_vol, int64_t n, double* h_stats, void* stream);
+
+/* ---- single-op entry points (parity tests drive each kernel through the ABI) -------------- */
+/* Conv3d k in {1,3}, stride 1, 'same' zero padding, on the split-f16 MFMA path.
+ * d_x f32[B][Cin][D][H][W] NCDHW, h_w f32[Cout][Cin][k][k][k], h_b f32[Cout] -> d_y f32[B][Cout][D][H][W]. */
+int mica_op_conv3d(mica_ctx* ctx, const float* d_x, int batch, int cin, int d, int h, int w,
+                   const float* h_w, const float* h_b, int cout, int k, float* d_y, void* stream);
+/* InstanceNorm3d(affine=False, eps=1e-5) + ReLU on NCDHW (model.py:81-82,108-109). */
+int mica_op_instnorm_relu(mica_ctx* ctx, const float* d_x, int batch, int c, int d, int h, int w,
+                          float* d_y, void* stream);
+/* Depthwise Conv3d(C,C,3,padding=1,groups=C) on NCDHW (model.py:80). */
+int mica_op_depthwise3(mica_ctx* ctx, const float* d_x, int batch, int c, int d, int h, int w,
+                       const float* h_w, const float* h_b, float* d_y, void* stream);
+/* The four Cin=1 stem convs k=3,5,7,9 -> 128 channels (model.py:9-14,49-51), NCDHW out.
+ * Uses the ctx's loaded input_processing.exp_convs.* weights.                                 */
+int mica_op_stem(mica_ctx* ctx, const float* d_map, int batch, int d, int h, int w, float* d_y, void* stream);
+
+/* ---- introspection for bench.py ----------------------------------------------------------- */
+/* Times (ms, HIP events on `stream`) of the dense-conv launches of the last forward when
+ * profiling was enabled with mica_set_profiling(ctx, 1): sum and launch count.               */
+int mica_set_profiling(mica_ctx* ctx, int enable);
+int mica_get_conv_profile(mica_ctx* ctx, double* h_ms_total, int64_t* h_launches, double* h_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICA_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libmica_hip.so (include/mica_hip.h).  Fails loudly when the library is
+missing: there is no CPU or PyTorch fallback behind this module."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmica_hip.so")
+
+MICA_OK = 0
+MICA_ERR_ARG, MICA_ERR_HIP, MICA_ERR_STATE, MICA_ERR_RANGE = -1, -2, -3, -4
+AF_NONE, AF_PER_TILE, AF_BATCH = 0, 1, 2
+
+_P = C.c_void_p
+_I, _L, _F = C.c_int, C.c_int64, C.c_float
+_FP = C.POINTER(C.c_float)
+_LP = C.POINTER(C.c_int64)
+_DP = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes): every symbol include/mica_hip.h declares
+SIGNATURES = {
+    "mica_abi_version": (_I, []),
+    "mica_create": (_I, [_I, _I, _I, C.POINTER(_P)]),
+    "mica_destroy": (None, [_P]),
+    "mica_last_error": (C.c_char_p, [_P]),
+    "mica_workspace_bytes": (_L, [_P]),
+    "mica_load_weight": (_I, [_P, C.c_char_p, _FP, _LP, _I]),
+    "mica_finalize_weights": (_I, [_P]),
+    "mica_forward_logits": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "mica_forward_tiles": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "mica_postprocess": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "mica_tile_count": (_L, [_L, _L, _L, _I]),
+    "mica_tile_table": (_L, [_L, _L, _L, _I, _LP, _L]),
+    "mica_gather_tiles": (_I, [_P, _P, _I, _L, _L, _L, _I, _I, _L, _L, _P, _P]),
+    "mica_stitch_tiles": (_I, [_P, _P, _I, _L, _L, _L, _I, _I, _L, _L, _P, _P]),
+    "mica_normalise_map": (_I, [_P, _P, _L, _DP, _P]),
+    "mica_op_conv3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _I, _P, _P]),
+    "mica_op_instnorm_relu": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "mica_op_depthwise3": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _P, _P]),
+    "mica_op_stem": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "mica_set_profiling": (_I, [_P, _I]),
+    "mica_get_conv_profile": (_I, [_P, _DP, _LP, _DP]),
+}
+
+_lib = None
+
+
+class MicaHipError(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None):
+    """dlopen libmica_hip.so and bind every declared symbol.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("MICA_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise MicaHipError(
+            f"{p} not found: build it with `make -C mica_amd/csrc` (or __graft_entry__.build()). "
+            "mica_amd has no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def tile_table(n0: int, n1: int, n2: int, grid: int):
+    """Host-side tile index table int64[T,6] = (i,j,k,di,dj,dk) (no GPU needed)."""
+    import numpy as np
+
+    lib = load_library()
+    t = lib.mica_tile_count(n0, n1, n2, grid)
+    if t < 0:
+        raise MicaHipError("mica_tile_count: bad argument")
+    tab = np.empty((t, 6), dtype=np.int64)
+    r = lib.mica_tile_table(n0, n1, n2, grid, tab.ctypes.data_as(_LP), t)
+    if r != t:
+        raise MicaHipError("mica_tile_table failed")
+    return tab

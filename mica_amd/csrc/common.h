@@ -1,0 +1,101 @@
+// Internal declarations shared by the HIP translation units of libmica_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace mica {
+
+// ---- activation formats ----------------------------------------------------------------------
+// raw   : float  [B][V][C]              (NDHWC, V = D*H*W voxels)
+// split : _Float16 [B][chunks][V][2][16]  a 16-channel chunk of one voxel is 64 B: 16 "hi" halves
+//         then 16 "lo" halves with  x * ASCALE = hi + lo (+ ~2^-22 relative).  This is what the
+//         MFMA conv consumes: three f16 MFMAs (hi*hi, hi*lo, lo*hi) give ~fp32 products.
+constexpr float ASCALE = 16.0f;          // activation pre-scale (keeps `lo` out of f16 subnormals)
+constexpr float INV_ASCALE = 1.0f / 16.0f;
+constexpr float F16_LIMIT = 60000.0f;    // |x*ASCALE| above this sets the range-error flag
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct SplitView {          // a channel-chunk window into a split buffer
+    _Float16* p;            // buffer base
+    int chunks_total;       // chunks per batch entry in the buffer
+    int chunk_off;          // first chunk of this view
+    int chunks;             // chunks in this view
+};
+
+constexpr int MAX_SRC = 4;
+struct ConvSrcs {
+    const _Float16* p[MAX_SRC];
+    int chunks_total[MAX_SRC];
+    int chunk_off[MAX_SRC];
+    int chunks[MAX_SRC];
+    int n;
+};
+
+struct Dims { int D, H, W; };  // one tile
+
+// ---- launchers (kernels_*.hip) -----------------------------------------------------------------
+// Dense conv (k=1 or 3) on split inputs.  wpk: packed weights [B?][chunks][taps][4][Cout][8] halves,
+// wpk_bstride = halves between batch entries (0 = shared).  out raw f32 [B][V][Cout]:
+// out = acc * out_scale + bias.
+void launch_conv_mfma(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
+                      float out_scale, float* out, int B, Dims d, int cout, int ksize, int* errflag,
+                      hipStream_t st);
+// Pack torch-layout conv weights into wpk.  seg_c/seg_cp: per-source real and padded channel counts.
+// cin_scale f32[B][Cin] (nullable) multiplies input channels (gate folding); cout_scale scalar.
+void launch_pack_weights(const float* w, int cout, int cin, int ksize, const int* h_seg_c, const int* h_seg_cp,
+                         int nseg, const float* cin_scale, int B, float cout_scale, float wscale,
+                         _Float16* wpk, hipStream_t st);
+int64_t packed_weight_halves(int cout, int ksize, int total_chunks);
+
+// raw f32 NDHWC [B][V][C] -> per (b,c) mean and rstd (biased var, eps) ; partial workspace ws
+void launch_stats(const float* x, int B, int V, int C, float eps, float* mean, float* rstd, float* ws,
+                  hipStream_t st);
+int64_t stats_ws_floats(int B, int C);
+// y = relu?((x-mean)*rstd) * scale ; writes split view and/or raw f32 ; optional per (b,c) mean of y (gap)
+void launch_prep(const float* x, int B, int V, int C, const float* mean, const float* rstd, int relu,
+                 const float* scale, SplitView out, float* out_raw, float* gap, float* ws, int* errflag,
+                 hipStream_t st);
+// NCDHW f32 [B][C][V] -> split (C padded to 16, zero filled) ; also per-batch |x| sum
+void launch_prep_ncdhw(const float* x, int B, int V, int C, SplitView out, float* abs_sum, int* errflag,
+                       hipStream_t st);
+void launch_finalize_sum(const float* ws, int B, int nblocks, int C, float inv, float* out, hipStream_t st);
+void launch_nchw_to_nhwc(const float* x, int B, int C, int V, float* y, hipStream_t st);
+void launch_nhwc_to_nchw(const float* x, int B, int C, int V, float* y, hipStream_t st);
+
+// gate[b][c] = sigmoid(W2 relu(W1 (pool[b]*premul[b]) + b1) + b2) ; out = gate * postmul (nullable)
+// gate_post (nullable) is written at gate_post[b*post_stride + c] (a slice of a conv's cin-scale row)
+void launch_gate_mlp(const float* pool, const float* premul, int B, int C, int Ch, const float* w1,
+                     const float* b1, const float* w2, const float* b2, const float* postmul, float* gate,
+                     float* gate_post, int post_stride, hipStream_t st);
+void launch_fill_float(float* p, int64_t n, float v, hipStream_t st);
+
+// depthwise 3^3 on raw input with fused (x-mean)*rstd, relu, *scale applied on load (zero padding after)
+void launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
+                      const float* scale, const float* w27, const float* bias, float* out, hipStream_t st);
+// stem: map f32 [B][V] -> split view of 128 channels + gap[b][128] (mean over voxels)
+void launch_stem(const float* map, int B, Dims d, const float* wstem, const float* bstem, SplitView out,
+                 float* out_raw, float* gap, float* ws, hipStream_t st);
+int64_t stem_weight_floats();
+// x_feat raw [B][V][64] -> split(x_feat * sigmoid(w2 . relu(W0 x + b0) + b2))
+void launch_feat_gate(const float* x, int B, int V, const float* w0, const float* b0, const float* w2,
+                      const float* b2, SplitView out, int* errflag, hipStream_t st);
+// head tail: raw2 [B][V][32] -> logits NCDHW [B][ncls][V] ; optional copy into split extras view at ch_off
+void launch_head_final(const float* x, int B, int V, const float* mean, const float* rstd, const float* gate,
+                       const float* wf, const float* bf, int ncls, float* logits, SplitView extra,
+                       int extra_ch_off, hipStream_t st);
+void launch_postprocess(const float* bb, const float* ca, const float* aa, int B, int V, float* bbp, float* cap,
+                        float* aap, float* aapred, hipStream_t st);
+void launch_fill_half(_Float16* p, int64_t n, hipStream_t st);
+
+void launch_gather_tiles(const float* vol, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
+                         int64_t first, int64_t count, float* tiles, hipStream_t st);
+void launch_stitch_tiles(const float* tiles, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
+                         int64_t first, int64_t count, float* vol, hipStream_t st);
+// exact order statistics of a f32 array (radix select) ; see kernels_select.hip
+int normalise_map_device(float* d_vol, int64_t n, double* h_stats, hipStream_t st, char* err, int errlen);
+
+}  // namespace mica

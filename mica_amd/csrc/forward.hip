@@ -1,0 +1,793 @@
+// Context, weight repacking and the forward graph of MICA (reference models/model.py:331-348) as a
+// fixed sequence of HIP kernel launches on one stream, behind the C ABI of include/mica_hip.h.
+#include "../../include/mica_hip.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mica;
+
+namespace {
+
+std::string g_create_err;
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct ConvLayer {
+    std::string name;
+    int cout = 0, cin = 0, k = 1;
+    std::vector<int> seg_c, seg_cp;   // channel segmentation of the (virtual) concatenated input
+    int total_chunks = 0;
+    float cout_scale = 1.f;           // folded output scale (FPN softmax weight, model.py:201-205)
+    float wscale = 1.f;               // power of two bringing max|w| to ~4096 (f16 hi/lo stay normal)
+    bool per_tile = false;            // weights re-packed per tile with a gate folded in (cin_scale)
+    float* d_w = nullptr;             // torch layout f32
+    float* d_b = nullptr;             // bias (already times cout_scale)
+    _Float16* d_wpk = nullptr;        // packed (static) or per-tile buffer [maxB][...]
+    float* d_cin_scale = nullptr;     // [maxB][cin] for per_tile layers
+    int64_t pk_halves = 0;
+    double flops_per_voxel = 0;
+};
+
+struct GateMLP {
+    int C = 0, Ch = 0;
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+};
+
+struct Enc {
+    int C;
+    ConvLayer conv1, conv2, conv3, fusion, transition;
+    GateMLP se, ga;
+    float *dw_w = nullptr, *dw_b = nullptr;   // [27][C], [C]
+};
+
+struct Head {
+    int ncls;
+    ConvLayer conv1, conv2;
+    GateMLP cal;
+    float *wf = nullptr, *bf = nullptr;
+};
+
+}  // namespace
+
+struct mica_ctx {
+    int device = 0, maxB = 1, S = 64;
+    Dims d{64, 64, 64};
+    int V = 0;
+    std::string err;
+    bool finalized = false;
+    std::map<std::string, HostTensor> host;
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+
+    // weights
+    float *stem_w = nullptr, *stem_b = nullptr;
+    GateMLP exp_att;
+    ConvLayer downsizing, feat_conv, fusion0;
+    float *fg_w0 = nullptr, *fg_b0 = nullptr, *fg_w2 = nullptr, *fg_b2 = nullptr;
+    Enc enc[3];
+    ConvLayer lateral[3], smooth[3];
+    Head heads[3];
+
+    // activations
+    _Float16 *S_exp, *S_af, *S_fw, *S_x0, *S_1, *S_2, *S_3, *S_dw, *S_f, *S_c[3], *S_l, *S_fpn, *S_extra, *S_h1;
+    float *R_a, *R_b, *R_c;
+    float *logits[3];             // internal NCDHW logits when the caller wants probabilities only
+    float* ws = nullptr;          // reduction partials
+    float *v_mean, *v_rstd, *v_mean3, *v_rstd3, *v_pool, *v_gse, *v_gate, *v_abs;
+    int* d_err = nullptr;
+    float* h_abs = nullptr;       // pinned
+    int* h_err = nullptr;         // pinned
+
+    // profiling of the dense-conv launches
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double prof_flops = 0;
+    double last_ms = 0, last_flops = 0;
+    int64_t last_launches = 0;
+};
+
+namespace {
+
+#define HIPC(ctx, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return MICA_ERR_HIP;                                                                     \
+        }                                                                                            \
+    } while (0)
+
+template <typename T> int dalloc(mica_ctx* c, T** p, int64_t n) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, (size_t)(n * (int64_t)sizeof(T)));
+    if (e != hipSuccess) {
+        c->err = "hipMalloc(" + std::to_string(n * (int64_t)sizeof(T)) + " B): " + hipGetErrorString(e);
+        return MICA_ERR_HIP;
+    }
+    c->allocs.push_back(q);
+    c->bytes += n * (int64_t)sizeof(T);
+    *p = (T*)q;
+    return MICA_OK;
+}
+
+int upload(mica_ctx* c, float** p, const std::vector<float>& h) {
+    int r = dalloc(c, p, (int64_t)h.size());
+    if (r) return r;
+    HIPC(c, hipMemcpy(*p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return MICA_OK;
+}
+
+const HostTensor* find(mica_ctx* c, const std::string& n) {
+    auto it = c->host.find(n);
+    return it == c->host.end() ? nullptr : &it->second;
+}
+
+bool shape_is(const HostTensor* t, std::initializer_list<int64_t> s) {
+    return t && t->shape == std::vector<int64_t>(s);
+}
+
+int pad16(int c) { return (c + 15) / 16 * 16; }
+
+// weight scale: power of two so that max|w * cout_scale| * wscale is in (2048, 4096]
+float pick_wscale(const std::vector<float>& w, float cs) {
+    float m = 0.f;
+    for (float v : w) m = std::fmax(m, std::fabs(v * cs));
+    if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
+    int e = 12 - (int)std::ceil(std::log2(m));
+    if (e > 24) e = 24;
+    if (e < -8) e = -8;
+    return std::ldexp(1.f, e);
+}
+
+int setup_conv(mica_ctx* c, ConvLayer& L, const std::string& name, int cout, int k, std::vector<int> seg_c, bool per_tile,
+               float cout_scale = 1.f) {
+    L.name = name;
+    L.cout = cout;
+    L.k = k;
+    L.seg_c = seg_c;
+    L.per_tile = per_tile;
+    L.cout_scale = cout_scale;
+    L.cin = 0;
+    L.seg_cp.clear();
+    L.total_chunks = 0;
+    for (int s : seg_c) {
+        L.cin += s;
+        L.seg_cp.push_back(pad16(s));
+        L.total_chunks += pad16(s) / 16;
+    }
+    const HostTensor* w = find(c, name + ".weight");
+    const HostTensor* b = find(c, name + ".bias");
+    if (!shape_is(w, {cout, L.cin, k, k, k}) || !shape_is(b, {cout})) {
+        c->err = "weight tensor missing or mis-shaped: " + name;
+        return MICA_ERR_STATE;
+    }
+    L.wscale = pick_wscale(w->data, cout_scale);
+    L.flops_per_voxel = 2.0 * k * k * k * (double)L.cin * cout;
+    int r = upload(c, &L.d_w, w->data);
+    if (r) return r;
+    std::vector<float> bs(b->data);
+    for (float& v : bs) v *= cout_scale;
+    r = upload(c, &L.d_b, bs);
+    if (r) return r;
+    L.pk_halves = packed_weight_halves(cout, k, L.total_chunks);
+    r = dalloc(c, &L.d_wpk, L.pk_halves * (per_tile ? c->maxB : 1));
+    if (r) return r;
+    if (per_tile) {
+        r = dalloc(c, &L.d_cin_scale, (int64_t)c->maxB * L.cin);
+        if (r) return r;
+        launch_fill_float(L.d_cin_scale, (int64_t)c->maxB * L.cin, 1.0f, 0);
+    } else {
+        launch_pack_weights(L.d_w, cout, L.cin, k, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(), nullptr, 1,
+                            cout_scale, L.wscale, L.d_wpk, 0);
+    }
+    return MICA_OK;
+}
+
+int setup_gate(mica_ctx* c, GateMLP& g, const std::string& n1, const std::string& n2, int C, int Ch, bool linear) {
+    g.C = C;
+    g.Ch = Ch;
+    const HostTensor *w1 = find(c, n1 + ".weight"), *b1 = find(c, n1 + ".bias");
+    const HostTensor *w2 = find(c, n2 + ".weight"), *b2 = find(c, n2 + ".bias");
+    bool ok = linear ? (shape_is(w1, {Ch, C}) && shape_is(w2, {C, Ch}))
+                     : (shape_is(w1, {Ch, C, 1, 1, 1}) && shape_is(w2, {C, Ch, 1, 1, 1}));
+    if (!ok || !shape_is(b1, {Ch}) || !shape_is(b2, {C})) {
+        c->err = "gate weights missing or mis-shaped: " + n1;
+        return MICA_ERR_STATE;
+    }
+    int r;
+    if ((r = upload(c, &g.w1, w1->data))) return r;
+    if ((r = upload(c, &g.b1, b1->data))) return r;
+    if ((r = upload(c, &g.w2, w2->data))) return r;
+    if ((r = upload(c, &g.b2, b2->data))) return r;
+    return MICA_OK;
+}
+
+SplitView view(_Float16* p, int chunks_total, int off, int chunks) { return SplitView{p, chunks_total, off, chunks}; }
+
+struct SrcList {
+    ConvSrcs s{};
+    SrcList() { s.n = 0; }
+    SrcList& add(const _Float16* p, int chunks_total, int off, int chunks) {
+        s.p[s.n] = p; s.chunks_total[s.n] = chunks_total; s.chunk_off[s.n] = off; s.chunks[s.n] = chunks; ++s.n;
+        return *this;
+    }
+};
+
+void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, hipStream_t st) {
+    if (L.per_tile)
+        launch_pack_weights(L.d_w, L.cout, L.cin, L.k, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(),
+                            L.d_cin_scale, B, L.cout_scale, L.wscale, L.d_wpk, st);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        while (c->ev.size() < c->ev_used + 2) { hipEvent_t e; hipEventCreate(&e); c->ev.push_back(e); }
+        e0 = c->ev[c->ev_used++]; e1 = c->ev[c->ev_used++];
+        hipEventRecord(e0, st);
+    }
+    launch_conv_mfma(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
+                     L.k, c->d_err, st);
+    if (c->profiling) {
+        hipEventRecord(e1, st);
+        c->prof_flops += L.flops_per_voxel * (double)c->V * B;
+    }
+}
+
+void gate(mica_ctx* c, const GateMLP& g, const float* pool, const float* premul, int B, const float* postmul, float* out,
+          float* out_post, int post_stride, hipStream_t st) {
+    launch_gate_mlp(pool, premul, B, g.C, g.Ch, g.w1, g.b1, g.w2, g.b2, postmul, out, out_post, post_stride, st);
+}
+
+// One run of tiles that share the AF branch (model.py:56-74).  Workspace slots 0..B-1.
+int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool use_af, float* o_bb, float* o_ca,
+                float* o_aa, hipStream_t st) {
+    const int V = c->V;
+    const Dims d = c->d;
+    SplitView none{nullptr, 0, 0, 0};
+    // ---- MultiScaleInput (model.py:43-74) ------------------------------------------------------
+    launch_stem(d_map, B, d, c->stem_w, c->stem_b, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, c->ws, st);
+    if (!use_af) {
+        gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->downsizing.d_cin_scale, 128, st);
+        run_conv(c, c->downsizing, SrcList().add(c->S_exp, 8, 0, 8), c->R_a, B, st);
+    } else {
+        gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->fusion0.d_cin_scale, 192, st);
+        launch_prep_ncdhw(d_af, B, V, 24, view(c->S_af, 2, 0, 2), nullptr, c->d_err, st);
+        run_conv(c, c->feat_conv, SrcList().add(c->S_af, 2, 0, 2), c->R_b, B, st);
+        launch_feat_gate(c->R_b, B, V, c->fg_w0, c->fg_b0, c->fg_w2, c->fg_b2, view(c->S_fw, 4, 0, 4), c->d_err, st);
+        run_conv(c, c->fusion0, SrcList().add(c->S_exp, 8, 0, 8).add(c->S_fw, 4, 0, 4), c->R_a, B, st);
+    }
+    launch_prep(c->R_a, B, V, 64, nullptr, nullptr, 0, nullptr, view(c->S_x0, 4, 0, 4), nullptr, nullptr, c->ws, c->d_err, st);
+
+    // ---- encoders (model.py:149-152) -----------------------------------------------------------
+    const _Float16* X = c->S_x0;
+    for (int e = 0; e < 3; ++e) {
+        Enc& E = c->enc[e];
+        const int C = E.C, cc = C / 16, ch = C / 32;   // chunks of C and of C/2
+        // ResidualDenseBlock (model.py:130-134)
+        run_conv(c, E.conv1, SrcList().add(X, cc, 0, cc), c->R_a, B, st);
+        launch_stats(c->R_a, B, V, C / 2, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        launch_prep(c->R_a, B, V, C / 2, c->v_mean, c->v_rstd, 1, nullptr, view(c->S_1, ch, 0, ch), nullptr, nullptr, c->ws, c->d_err, st);
+        run_conv(c, E.conv2, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch), c->R_a, B, st);
+        launch_stats(c->R_a, B, V, C / 2, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        launch_prep(c->R_a, B, V, C / 2, c->v_mean, c->v_rstd, 1, nullptr, view(c->S_2, ch, 0, ch), nullptr, nullptr, c->ws, c->d_err, st);
+        run_conv(c, E.conv3, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch).add(c->S_2, ch, 0, ch), c->R_b, B, st);
+        launch_stats(c->R_b, B, V, C, 1e-5f, c->v_mean3, c->v_rstd3, c->ws, st);
+        launch_prep(c->R_b, B, V, C, c->v_mean3, c->v_rstd3, 1, nullptr, view(c->S_3, cc, 0, cc), nullptr, c->v_pool, c->ws, c->d_err, st);
+        // SEBlock gate (model.py:254-258); applied downstream: folded into the depthwise load and the fusion weights
+        gate(c, E.se, c->v_pool, nullptr, B, nullptr, c->v_gse, nullptr, 0, st);
+        // DualAttention (model.py:98-101): local branch
+        launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, c->v_gse, E.dw_w, E.dw_b, c->R_c, st);
+        launch_stats(c->R_c, B, V, C, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        launch_prep(c->R_c, B, V, C, c->v_mean, c->v_rstd, 1, nullptr, view(c->S_dw, cc, 0, cc), nullptr, nullptr, c->ws, c->d_err, st);
+        // global branch: GAP(se(x3)) = g_se * GAP(x3); global_feat = g_ga * g_se * x3 folded into fusion's weights
+        gate(c, E.ga, c->v_pool, c->v_gse, B, c->v_gse, nullptr, E.fusion.d_cin_scale + C, 2 * C, st);
+        run_conv(c, E.fusion, SrcList().add(c->S_dw, cc, 0, cc).add(c->S_3, cc, 0, cc), c->R_a, B, st);
+        launch_prep(c->R_a, B, V, C, nullptr, nullptr, 0, nullptr, view(c->S_f, cc, 0, cc), nullptr, nullptr, c->ws, c->d_err, st);
+        // transition (model.py:141-147)
+        run_conv(c, E.transition, SrcList().add(c->S_f, cc, 0, cc), c->R_a, B, st);
+        launch_stats(c->R_a, B, V, 2 * C, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        launch_prep(c->R_a, B, V, 2 * C, c->v_mean, c->v_rstd, 1, nullptr, view(c->S_c[e], 2 * cc, 0, 2 * cc), nullptr, nullptr, c->ws, c->d_err, st);
+        X = c->S_c[e];
+    }
+    // ---- FPN (model.py:182-205; the interpolations are identities) ------------------------------
+    for (int i = 0; i < 3; ++i) {
+        const int cc = (128 << i) / 16;
+        run_conv(c, c->lateral[i], SrcList().add(c->S_c[i], cc, 0, cc), c->R_a, B, st);
+        launch_prep(c->R_a, B, V, 64, nullptr, nullptr, 0, nullptr, view(c->S_l, 4, 0, 4), nullptr, nullptr, c->ws, c->d_err, st);
+        run_conv(c, c->smooth[i], SrcList().add(c->S_l, 4, 0, 4), c->R_b, B, st);
+        launch_prep(c->R_b, B, V, 64, nullptr, nullptr, 0, nullptr, view(c->S_fpn, 12, 4 * i, 4), nullptr, nullptr, c->ws, c->d_err, st);
+    }
+    // ---- heads (model.py:230-239, 344-346) ------------------------------------------------------
+    launch_fill_half(c->S_extra, (int64_t)B * V * 32, st);
+    float* outs[3] = {o_bb, o_ca, o_aa};
+    for (int h = 0; h < 3; ++h) {
+        Head& H = c->heads[h];
+        SrcList src;
+        src.add(c->S_fpn, 12, 0, 12);
+        if (h > 0) src.add(c->S_extra, 1, 0, 1);
+        run_conv(c, H.conv1, src, c->R_a, B, st);
+        launch_stats(c->R_a, B, V, 64, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        launch_prep(c->R_a, B, V, 64, c->v_mean, c->v_rstd, 1, nullptr, view(c->S_h1, 4, 0, 4), nullptr, nullptr, c->ws, c->d_err, st);
+        run_conv(c, H.conv2, SrcList().add(c->S_h1, 4, 0, 4), c->R_b, B, st);
+        launch_stats(c->R_b, B, V, 32, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        launch_prep(c->R_b, B, V, 32, c->v_mean, c->v_rstd, 1, nullptr, none, nullptr, c->v_pool, c->ws, c->d_err, st);
+        gate(c, H.cal, c->v_pool, nullptr, B, nullptr, c->v_gate, nullptr, 0, st);
+        launch_head_final(c->R_b, B, V, c->v_mean, c->v_rstd, c->v_gate, H.wf, H.bf, H.ncls, outs[h],
+                          h < 2 ? view(c->S_extra, 1, 0, 1) : none, 4 * h, st);
+    }
+    return MICA_OK;
+}
+
+int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int af_mode, float* o_bb, float* o_ca, float* o_aa,
+                 hipStream_t st) {
+    if (!c->finalized) { c->err = "weights not finalized"; return MICA_ERR_STATE; }
+    if (B < 1 || B > c->maxB) { c->err = "batch out of range [1, max_batch]"; return MICA_ERR_ARG; }
+    if (!d_map || !o_bb || !o_ca || !o_aa) { c->err = "null pointer argument"; return MICA_ERR_ARG; }
+    if (af_mode != MICA_AF_NONE && af_mode != MICA_AF_PER_TILE && af_mode != MICA_AF_BATCH) { c->err = "bad af_mode"; return MICA_ERR_ARG; }
+    HIPC(c, hipSetDevice(c->device));
+    const int V = c->V;
+    c->ev_used = 0;
+    c->prof_flops = 0;
+    HIPC(c, hipMemsetAsync(c->d_err, 0, sizeof(int), st));
+    std::vector<char> use(B, 0);
+    if (d_af && af_mode != MICA_AF_NONE) {
+        // is_af_zero = af.abs().sum() < 1e-6  (model.py:60): device reduction, one small D2H per call
+        HIPC(c, hipMemsetAsync(c->v_abs, 0, sizeof(float) * B, st));
+        launch_prep_ncdhw(d_af, B, V, 24, SplitView{nullptr, 0, 0, 0}, c->v_abs, c->d_err, st);
+        HIPC(c, hipMemcpyAsync(c->h_abs, c->v_abs, sizeof(float) * B, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipStreamSynchronize(st));
+        if (af_mode == MICA_AF_BATCH) {
+            double tot = 0;
+            for (int b = 0; b < B; ++b) tot += c->h_abs[b];
+            for (int b = 0; b < B; ++b) use[b] = !(tot < 1e-6);
+        } else {
+            for (int b = 0; b < B; ++b) use[b] = !(c->h_abs[b] < 1e-6f);
+        }
+    }
+    for (int b0 = 0; b0 < B;) {
+        int b1 = b0 + 1;
+        while (b1 < B && use[b1] == use[b0]) ++b1;
+        int r = forward_run(c, d_map + (int64_t)b0 * V, d_af ? d_af + (int64_t)b0 * 24 * V : nullptr, b1 - b0, use[b0] != 0,
+                            o_bb + (int64_t)b0 * 4 * V, o_ca + (int64_t)b0 * 4 * V, o_aa + (int64_t)b0 * 21 * V, st);
+        if (r) return r;
+        b0 = b1;
+    }
+    HIPC(c, hipGetLastError());
+    if (c->profiling) {
+        HIPC(c, hipStreamSynchronize(st));
+        double ms = 0;
+        for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+            float t = 0;
+            hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]);
+            ms += t;
+        }
+        c->last_ms = ms;
+        c->last_launches = (int64_t)(c->ev_used / 2);
+        c->last_flops = c->prof_flops;
+    }
+    return MICA_OK;
+}
+
+}  // namespace
+
+namespace {
+struct Tmp {
+    std::vector<void*> p;
+    ~Tmp() { for (void* q : p) hipFree(q); }
+    template <typename T> T* get(int64_t n) {
+        void* q = nullptr;
+        if (hipMalloc(&q, (size_t)(n * (int64_t)sizeof(T))) != hipSuccess) return nullptr;
+        p.push_back(q);
+        return (T*)q;
+    }
+};
+bool pow2_8_512(int c) { return c >= 8 && c <= 512 && (c & (c - 1)) == 0; }
+}  // namespace
+
+
+// =================================================================================================
+extern "C" {
+
+int mica_abi_version(void) { return 1; }
+
+const char* mica_last_error(const mica_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int64_t mica_workspace_bytes(const mica_ctx* ctx) { return ctx ? ctx->bytes : 0; }
+
+int mica_create(int device, int max_batch, int tile_size, mica_ctx** out) {
+    if (!out || max_batch < 1 || max_batch > 64 || tile_size < 4 || tile_size > 128) {
+        g_create_err = "mica_create: bad argument";
+        return MICA_ERR_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || device < 0 || device >= ndev) {
+        g_create_err = std::string("mica_create: no such HIP device (") + hipGetErrorString(e) + ")";
+        return MICA_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    hipSetDevice(device);
+    hipGetDeviceProperties(&prop, device);
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        g_create_err = std::string("mica_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return MICA_ERR_HIP;
+    }
+    mica_ctx* c = new mica_ctx();
+    c->device = device;
+    c->maxB = max_batch;
+    c->S = tile_size;
+    c->d = Dims{tile_size, tile_size, tile_size};
+    c->V = tile_size * tile_size * tile_size;
+    const int64_t BV = (int64_t)max_batch * c->V;
+    int r = 0;
+    auto S = [&](_Float16** p, int ch) { if (!r) r = dalloc(c, p, BV * ch * 2); };   // hi + lo
+    S(&c->S_exp, 128); S(&c->S_af, 32); S(&c->S_fw, 64); S(&c->S_x0, 64);
+    S(&c->S_1, 128); S(&c->S_2, 128); S(&c->S_3, 256); S(&c->S_dw, 256); S(&c->S_f, 256);
+    S(&c->S_c[0], 128); S(&c->S_c[1], 256); S(&c->S_c[2], 512);
+    S(&c->S_l, 64); S(&c->S_fpn, 192); S(&c->S_extra, 16); S(&c->S_h1, 64);
+    auto R = [&](float** p, int ch) { if (!r) r = dalloc(c, p, BV * ch); };
+    R(&c->R_a, 512); R(&c->R_b, 256); R(&c->R_c, 256);
+    R(&c->logits[0], 4); R(&c->logits[1], 4); R(&c->logits[2], 21);
+    int64_t wsn = stats_ws_floats(max_batch, 512);
+    int64_t stem_ws = (int64_t)max_batch * 128 * (((tile_size + 31) / 32) * ((tile_size + 7) / 8) * ((tile_size + 1) / 2));
+    if (stem_ws > wsn) wsn = stem_ws;
+    if (!r) r = dalloc(c, &c->ws, wsn);
+    auto Vv = [&](float** p) { if (!r) r = dalloc(c, p, (int64_t)max_batch * 512); };
+    Vv(&c->v_mean); Vv(&c->v_rstd); Vv(&c->v_mean3); Vv(&c->v_rstd3); Vv(&c->v_pool); Vv(&c->v_gse); Vv(&c->v_gate); Vv(&c->v_abs);
+    if (!r) r = dalloc(c, &c->d_err, 4);
+    if (!r && hipHostMalloc((void**)&c->h_abs, sizeof(float) * max_batch) != hipSuccess) { c->err = "hipHostMalloc failed"; r = MICA_ERR_HIP; }
+    if (!r && hipHostMalloc((void**)&c->h_err, sizeof(int)) != hipSuccess) { c->err = "hipHostMalloc failed"; r = MICA_ERR_HIP; }
+    if (r) {
+        g_create_err = "mica_create: " + c->err;
+        mica_destroy(c);
+        return r;
+    }
+    *out = c;
+    return MICA_OK;
+}
+
+void mica_destroy(mica_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (void* p : c->allocs) hipFree(p);
+    if (c->h_abs) hipHostFree(c->h_abs);
+    if (c->h_err) hipHostFree(c->h_err);
+    for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    delete c;
+}
+
+int mica_load_weight(mica_ctx* c, const char* name, const float* h_data, const int64_t* shape, int ndim) {
+    if (!c) return MICA_ERR_ARG;
+    if (!name || !h_data || !shape || ndim < 1 || ndim > 5) { c->err = "mica_load_weight: bad argument"; return MICA_ERR_ARG; }
+    if (c->finalized) { c->err = "mica_load_weight: weights already finalized"; return MICA_ERR_STATE; }
+    HostTensor t;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= shape[i]; }
+    if (n < 1 || n > (int64_t)1 << 28) { c->err = "mica_load_weight: bad shape"; return MICA_ERR_ARG; }
+    t.data.assign(h_data, h_data + n);
+    for (float v : t.data)
+        if (!std::isfinite(v)) { c->err = std::string("mica_load_weight: non-finite value in ") + name; return MICA_ERR_ARG; }
+    std::string key(name);
+    if (key.rfind("module.", 0) == 0) key = key.substr(7);   // DataParallel prefix (predict.py:237-238)
+    c->host[key] = std::move(t);
+    return MICA_OK;
+}
+
+int mica_finalize_weights(mica_ctx* c) {
+    if (!c) return MICA_ERR_ARG;
+    if (c->finalized) { c->err = "already finalized"; return MICA_ERR_STATE; }
+    HIPC(c, hipSetDevice(c->device));
+    int r;
+    const std::string ip = "input_processing.";
+    // stem: [32][1][k][k][k] x4 -> [conv][tap][32]
+    {
+        std::vector<float> w((size_t)stem_weight_floats()), b(128);
+        size_t off = 0;
+        const int ks[4] = {3, 5, 7, 9};
+        for (int i = 0; i < 4; ++i) {
+            const int k = ks[i], nt = k * k * k;
+            const HostTensor* tw = find(c, ip + "exp_convs." + std::to_string(i) + ".weight");
+            const HostTensor* tb = find(c, ip + "exp_convs." + std::to_string(i) + ".bias");
+            if (!shape_is(tw, {32, 1, k, k, k}) || !shape_is(tb, {32})) { c->err = "stem conv weights missing or mis-shaped"; return MICA_ERR_STATE; }
+            for (int t = 0; t < nt; ++t)
+                for (int co = 0; co < 32; ++co) w[off + (size_t)t * 32 + co] = tw->data[(size_t)co * nt + t];
+            for (int co = 0; co < 32; ++co) b[i * 32 + co] = tb->data[co];
+            off += (size_t)nt * 32;
+        }
+        if ((r = upload(c, &c->stem_w, w))) return r;
+        if ((r = upload(c, &c->stem_b, b))) return r;
+    }
+    if ((r = setup_gate(c, c->exp_att, ip + "exp_attention.1", ip + "exp_attention.3", 128, 64, false))) return r;
+    if ((r = setup_conv(c, c->downsizing, ip + "exp_downsizing", 64, 1, {128}, true))) return r;
+    if ((r = setup_conv(c, c->feat_conv, ip + "feat_conv", 64, 3, {24}, false))) return r;
+    if ((r = setup_conv(c, c->fusion0, ip + "fusion", 64, 1, {128, 64}, true))) return r;
+    {
+        const HostTensor *w0 = find(c, ip + "feat_gate.0.weight"), *b0 = find(c, ip + "feat_gate.0.bias");
+        const HostTensor *w2 = find(c, ip + "feat_gate.2.weight"), *b2 = find(c, ip + "feat_gate.2.bias");
+        if (!shape_is(w0, {16, 64, 1, 1, 1}) || !shape_is(b0, {16}) || !shape_is(w2, {1, 16, 1, 1, 1}) || !shape_is(b2, {1})) {
+            c->err = "feat_gate weights missing or mis-shaped";
+            return MICA_ERR_STATE;
+        }
+        if ((r = upload(c, &c->fg_w0, w0->data))) return r;
+        if ((r = upload(c, &c->fg_b0, b0->data))) return r;
+        if ((r = upload(c, &c->fg_w2, w2->data))) return r;
+        if ((r = upload(c, &c->fg_b2, b2->data))) return r;
+    }
+    for (int e = 0; e < 3; ++e) {
+        Enc& E = c->enc[e];
+        const int C = 64 << e;
+        E.C = C;
+        const std::string p = "encoder." + std::to_string(e) + ".";
+        if ((r = setup_conv(c, E.conv1, p + "dense_block.conv1.0", C / 2, 3, {C}, false))) return r;
+        if ((r = setup_conv(c, E.conv2, p + "dense_block.conv2.0", C / 2, 3, {C, C / 2}, false))) return r;
+        if ((r = setup_conv(c, E.conv3, p + "dense_block.conv3.0", C, 3, {C, C / 2, C / 2}, false))) return r;
+        if ((r = setup_gate(c, E.se, p + "dense_block.se.fc.0", p + "dense_block.se.fc.3", C, C / 16, true))) return r;
+        if ((r = setup_gate(c, E.ga, p + "dual_attn.global_attn.1", p + "dual_attn.global_attn.4", C, C / 4, false))) return r;
+        if ((r = setup_conv(c, E.fusion, p + "dual_attn.fusion", C, 1, {C, C}, true))) return r;
+        if ((r = setup_conv(c, E.transition, p + "transition.0", 2 * C, 3, {C}, false))) return r;
+        const HostTensor *dw = find(c, p + "dual_attn.local_attn.0.weight"), *db = find(c, p + "dual_attn.local_attn.0.bias");
+        if (!shape_is(dw, {C, 1, 3, 3, 3}) || !shape_is(db, {C})) { c->err = "depthwise weights missing or mis-shaped"; return MICA_ERR_STATE; }
+        std::vector<float> wt((size_t)27 * C);
+        for (int ch = 0; ch < C; ++ch)
+            for (int t = 0; t < 27; ++t) wt[(size_t)t * C + ch] = dw->data[(size_t)ch * 27 + t];
+        if ((r = upload(c, &E.dw_w, wt))) return r;
+        if ((r = upload(c, &E.dw_b, db->data))) return r;
+    }
+    {
+        const HostTensor* fw = find(c, "fpn.weights");
+        if (!shape_is(fw, {3})) { c->err = "fpn.weights missing or mis-shaped"; return MICA_ERR_STATE; }
+        // softmax over the three fusion weights (model.py:183), f32 like torch
+        float m = std::fmax(fw->data[0], std::fmax(fw->data[1], fw->data[2]));
+        float ex[3], s = 0.f;
+        for (int i = 0; i < 3; ++i) { ex[i] = std::exp(fw->data[i] - m); s += ex[i]; }
+        for (int i = 0; i < 3; ++i) {
+            if ((r = setup_conv(c, c->lateral[i], "fpn.lateral." + std::to_string(i), 64, 1, {128 << i}, false))) return r;
+            if ((r = setup_conv(c, c->smooth[i], "fpn.smooth." + std::to_string(i) + ".0", 64, 3, {64}, false, ex[i] / s))) return r;
+        }
+    }
+    const char* hn[3] = {"backbone_head", "ca_head", "aa_head"};
+    const int ncls[3] = {4, 4, 21};
+    for (int h = 0; h < 3; ++h) {
+        Head& H = c->heads[h];
+        H.ncls = ncls[h];
+        const std::string p = std::string(hn[h]) + ".";
+        std::vector<int> seg = {192};
+        if (h > 0) seg.push_back(4 * h);
+        if ((r = setup_conv(c, H.conv1, p + "conv1", 64, 3, seg, false))) return r;
+        if ((r = setup_conv(c, H.conv2, p + "conv2", 32, 3, {64}, false))) return r;
+        if ((r = setup_gate(c, H.cal, p + "calibration.1", p + "calibration.4", 32, 8, false))) return r;
+        const HostTensor *wf = find(c, p + "final.weight"), *bf = find(c, p + "final.bias");
+        if (!shape_is(wf, {ncls[h], 32, 1, 1, 1}) || !shape_is(bf, {ncls[h]})) { c->err = "head final weights missing or mis-shaped"; return MICA_ERR_STATE; }
+        if ((r = upload(c, &H.wf, wf->data))) return r;
+        if ((r = upload(c, &H.bf, bf->data))) return r;
+    }
+    HIPC(c, hipDeviceSynchronize());
+    HIPC(c, hipGetLastError());
+    c->host.clear();
+    c->finalized = true;
+    return MICA_OK;
+}
+
+int mica_forward_logits(mica_ctx* c, const float* d_map, const float* d_af, int batch, int af_mode, float* d_bb, float* d_ca,
+                        float* d_aa, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int r = forward_impl(c, d_map, d_af, batch, af_mode, d_bb, d_ca, d_aa, st);
+    return r;
+}
+
+int mica_postprocess(mica_ctx* c, const float* d_bb, const float* d_ca, const float* d_aa, int batch, float* d_bb_prob,
+                     float* d_ca_prob, float* d_aa_prob, float* d_aa_pred, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_bb || !d_ca || !d_aa || !d_bb_prob || !d_ca_prob || !d_aa_prob || !d_aa_pred || batch < 1) { c->err = "mica_postprocess: bad argument"; return MICA_ERR_ARG; }
+    HIPC(c, hipSetDevice(c->device));
+    launch_postprocess(d_bb, d_ca, d_aa, batch, c->V, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return MICA_OK;
+}
+
+int mica_forward_tiles(mica_ctx* c, const float* d_map, const float* d_af, int batch, int af_mode, float* d_bb_prob,
+                       float* d_ca_prob, float* d_aa_prob, float* d_aa_pred, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int r = forward_impl(c, d_map, d_af, batch, af_mode, c->logits[0], c->logits[1], c->logits[2], st);
+    if (r) return r;
+    r = mica_postprocess(c, c->logits[0], c->logits[1], c->logits[2], batch, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, stream);
+    if (r) return r;
+    // range check of the split-f16 encoding: fail loudly rather than return clipped activations
+    HIPC(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPC(c, hipStreamSynchronize(st));
+    if (*c->h_err) { c->err = "activation outside the representable range of the split-f16 conv path (|x| > 3750 or NaN)"; return MICA_ERR_RANGE; }
+    return MICA_OK;
+}
+
+int64_t mica_tile_count(int64_t n0, int64_t n1, int64_t n2, int grid) {
+    if (n0 < 1 || n1 < 1 || n2 < 1 || grid < 1) return MICA_ERR_ARG;
+    return ((n0 + grid - 1) / grid) * ((n1 + grid - 1) / grid) * ((n2 + grid - 1) / grid);
+}
+
+int64_t mica_tile_table(int64_t n0, int64_t n1, int64_t n2, int grid, int64_t* h_table, int64_t capacity) {
+    int64_t T = mica_tile_count(n0, n1, n2, grid);
+    if (T < 0 || !h_table || capacity < T) return MICA_ERR_ARG;
+    int64_t t = 0;
+    for (int64_t i = 0; i < n0; i += grid)           // create_grids.py:143-149
+        for (int64_t j = 0; j < n1; j += grid)
+            for (int64_t k = 0; k < n2; k += grid) {
+                int64_t* r = h_table + 6 * t++;
+                r[0] = i; r[1] = j; r[2] = k;
+                r[3] = (n0 - i < grid) ? n0 - i : grid;
+                r[4] = (n1 - j < grid) ? n1 - j : grid;
+                r[5] = (n2 - k < grid) ? n2 - k : grid;
+            }
+    return T;
+}
+
+static int check_tiling(mica_ctx* c, const void* a, const void* b, int channels, int64_t n0, int64_t n1, int64_t n2, int grid,
+                        int pad, int64_t first, int64_t count) {
+    if (!a || !b || channels < 1 || channels > 65535 || grid < 1 || pad < 0 || count < 0 || count > 65535 || first < 0) {
+        c->err = "tiling: bad argument";
+        return MICA_ERR_ARG;
+    }
+    int64_t T = mica_tile_count(n0, n1, n2, grid);
+    if (T < 0 || first + count > T) { c->err = "tiling: tile range outside the table"; return MICA_ERR_ARG; }
+    return MICA_OK;
+}
+
+int mica_gather_tiles(mica_ctx* c, const float* d_vol, int channels, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
+                      int64_t first, int64_t count, float* d_tiles, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    int r = check_tiling(c, d_vol, d_tiles, channels, n0, n1, n2, grid, pad, first, count);
+    if (r || count == 0) return r;
+    HIPC(c, hipSetDevice(c->device));
+    launch_gather_tiles(d_vol, channels, n0, n1, n2, grid, pad, first, count, d_tiles, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return MICA_OK;
+}
+
+int mica_stitch_tiles(mica_ctx* c, const float* d_tiles, int channels, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
+                      int64_t first, int64_t count, float* d_vol, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    int r = check_tiling(c, d_tiles, d_vol, channels, n0, n1, n2, grid, pad, first, count);
+    if (r || count == 0) return r;
+    HIPC(c, hipSetDevice(c->device));
+    launch_stitch_tiles(d_tiles, channels, n0, n1, n2, grid, pad, first, count, d_vol, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return MICA_OK;
+}
+
+int mica_normalise_map(mica_ctx* c, float* d_vol, int64_t n, double* h_stats, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_vol || n < 1 || !h_stats) { c->err = "mica_normalise_map: bad argument"; return MICA_ERR_ARG; }
+    HIPC(c, hipSetDevice(c->device));
+    char buf[256] = {0};
+    int r = normalise_map_device(d_vol, n, h_stats, (hipStream_t)stream, buf, sizeof(buf));
+    if (r) c->err = buf;
+    return r;
+}
+
+// ---- single-op entry points (test harness for the individual kernels) ---------------------------
+int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w, const float* h_b,
+                   int cout, int k, float* d_y, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_x || !h_w || !h_b || !d_y || batch < 1 || cin < 1 || cout < 32 || cout % 32 || (k != 1 && k != 3) || d < 1 || h < 1 || w < 1) {
+        c->err = "mica_op_conv3d: bad argument (cout must be a multiple of 32, k in {1,3})";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int V = d * h * w, cp = pad16(cin), nt = k * k * k;
+    Tmp t;
+    _Float16* sx = t.get<_Float16>((int64_t)batch * V * cp * 2);
+    float* dw = t.get<float>((int64_t)cout * cin * nt);
+    float* db = t.get<float>(cout);
+    float* raw = t.get<float>((int64_t)batch * V * cout);
+    _Float16* pk = t.get<_Float16>(packed_weight_halves(cout, k, cp / 16));
+    int* derr = t.get<int>(1);
+    if (!sx || !dw || !db || !raw || !pk || !derr) { c->err = "mica_op_conv3d: hipMalloc failed"; return MICA_ERR_HIP; }
+    std::vector<float> hw(h_w, h_w + (size_t)cout * cin * nt);
+    float ws = pick_wscale(hw, 1.f);
+    HIPC(c, hipMemcpyAsync(dw, h_w, sizeof(float) * cout * cin * nt, hipMemcpyHostToDevice, st));
+    HIPC(c, hipMemcpyAsync(db, h_b, sizeof(float) * cout, hipMemcpyHostToDevice, st));
+    HIPC(c, hipMemsetAsync(derr, 0, 4, st));
+    launch_prep_ncdhw(d_x, batch, V, cin, SplitView{sx, cp / 16, 0, cp / 16}, nullptr, derr, st);
+    int sc[1] = {cin}, scp[1] = {cp};
+    launch_pack_weights(dw, cout, cin, k, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
+    ConvSrcs s{};
+    s.n = 1; s.p[0] = sx; s.chunks_total[0] = cp / 16; s.chunk_off[0] = 0; s.chunks[0] = cp / 16;
+    launch_conv_mfma(s, pk, 0, db, 1.0f / (ws * ASCALE), raw, batch, Dims{d, h, w}, cout, k, derr, st);
+    launch_nhwc_to_nchw(raw, batch, cout, V, d_y, st);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(st));
+    return MICA_OK;
+}
+
+int mica_op_instnorm_relu(mica_ctx* c, const float* d_x, int batch, int ch, int d, int h, int w, float* d_y, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_x || !d_y || batch < 1 || !pow2_8_512(ch) || d < 1 || h < 1 || w < 1) { c->err = "mica_op_instnorm_relu: bad argument (C must be a power of two in [8,512])"; return MICA_ERR_ARG; }
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int V = d * h * w;
+    Tmp t;
+    float* a = t.get<float>((int64_t)batch * V * ch);
+    float* b = t.get<float>((int64_t)batch * V * ch);
+    float* mean = t.get<float>((int64_t)batch * ch);
+    float* rstd = t.get<float>((int64_t)batch * ch);
+    float* ws = t.get<float>(stats_ws_floats(batch, ch));
+    int* derr = t.get<int>(1);
+    if (!a || !b || !mean || !rstd || !ws || !derr) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
+    launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
+    launch_stats(a, batch, V, ch, 1e-5f, mean, rstd, ws, st);
+    launch_prep(a, batch, V, ch, mean, rstd, 1, nullptr, SplitView{nullptr, 0, 0, 0}, b, nullptr, ws, derr, st);
+    launch_nhwc_to_nchw(b, batch, ch, V, d_y, st);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(st));
+    return MICA_OK;
+}
+
+int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, int h, int w, const float* h_w, const float* h_b,
+                       float* d_y, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_x || !d_y || !h_w || !h_b || batch < 1 || ch < 4 || ch % 4 || d < 1 || h < 1 || w < 1) { c->err = "mica_op_depthwise3: bad argument"; return MICA_ERR_ARG; }
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int V = d * h * w;
+    Tmp t;
+    float* a = t.get<float>((int64_t)batch * V * ch);
+    float* b = t.get<float>((int64_t)batch * V * ch);
+    float* dw = t.get<float>(27 * ch);
+    float* db = t.get<float>(ch);
+    if (!a || !b || !dw || !db) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
+    std::vector<float> wt((size_t)27 * ch);
+    for (int cc = 0; cc < ch; ++cc)
+        for (int tp = 0; tp < 27; ++tp) wt[(size_t)tp * ch + cc] = h_w[(size_t)cc * 27 + tp];
+    HIPC(c, hipMemcpy(dw, wt.data(), sizeof(float) * 27 * ch, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(db, h_b, sizeof(float) * ch, hipMemcpyHostToDevice));
+    launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
+    launch_depthwise(a, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, st);
+    launch_nhwc_to_nchw(b, batch, ch, V, d_y, st);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(st));
+    return MICA_OK;
+}
+
+int mica_op_stem(mica_ctx* c, const float* d_map, int batch, int d, int h, int w, float* d_y, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!c->finalized) { c->err = "weights not finalized"; return MICA_ERR_STATE; }
+    if (!d_map || !d_y || batch < 1 || d < 1 || h < 1 || w < 1) { c->err = "mica_op_stem: bad argument"; return MICA_ERR_ARG; }
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int V = d * h * w;
+    Tmp t;
+    float* raw = t.get<float>((int64_t)batch * V * 128);
+    if (!raw) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
+    launch_stem(d_map, batch, Dims{d, h, w}, c->stem_w, c->stem_b, SplitView{nullptr, 0, 0, 0}, raw, nullptr, nullptr, st);
+    launch_nhwc_to_nchw(raw, batch, 128, V, d_y, st);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(st));
+    return MICA_OK;
+}
+
+int mica_set_profiling(mica_ctx* c, int enable) {
+    if (!c) return MICA_ERR_ARG;
+    c->profiling = enable != 0;
+    return MICA_OK;
+}
+
+int mica_get_conv_profile(mica_ctx* c, double* h_ms_total, int64_t* h_launches, double* h_flops) {
+    if (!c || !h_ms_total || !h_launches || !h_flops) return MICA_ERR_ARG;
+    *h_ms_total = c->last_ms;
+    *h_launches = c->last_launches;
+    *h_flops = c->last_flops;
+    return MICA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,447 @@
+// Dense convolution on gfx950 matrix cores: implicit GEMM over 16-channel chunks with split-f16
+// operands (x = hi + lo, three v_mfma_f32_32x32x16_f16 per product: lo*hi, hi*lo, hi*hi), which keeps
+// ~22 mantissa bits per product at 3/16 of the f32-MFMA cost (MI355X: f32 MFMA 157 TF, f16 2.5 PF).
+// Replaces nn.Conv3d(k=3,pad=1) / nn.Conv3d(k=1) of reference models/model.py:17,28,38,96,107,115,122,
+// 142,158-174,210,212.  Also: weight packing, depthwise 3^3 (model.py:80) and the Cin=1 multi-scale
+// stem (model.py:9-14).
+#include "common.h"
+
+namespace mica {
+
+// ------------------------------------------------------------------------------------------------
+// Geometry of one workgroup (256 threads = 4 waves): output tile 16(x) x 8(y) x 2(z) voxels = 256 GEMM
+// rows, BN output channels.  Wave w owns rows y = 2w, 2w+1; an MFMA row-fragment (32 rows) is the 16 x
+// of one y in both z planes, which makes every ds_read_b128 lane group hit 16 distinct 16-B LDS slots
+// (the z-plane stride is padded to a multiple of 16 slots).
+// LDS A image: 4 planes q = kind*2 + khalf (kind: hi/lo, khalf: channels 0-7 / 8-15 of the chunk), each
+// [SZ][PZ] slots of 16 B (8 halves); slot = vz*PZ + vy*SX + vx.
+// ------------------------------------------------------------------------------------------------
+template <int KS> struct Geo {
+    static constexpr int HALO = KS / 2;
+    static constexpr int SX = 16 + 2 * HALO, SY = 8 + 2 * HALO, SZ = 2 + 2 * HALO;
+    static constexpr int PZ = ((SX * SY + 15) / 16) * 16;     // slots per z plane, = 0 mod 16
+    static constexpr int PLANE = SZ * PZ;                     // slots per q plane
+    static constexpr int A_BYTES = 4 * PLANE * 16;
+    static constexpr int NT = KS * KS * KS;
+    static constexpr int ROW_PIECES = SX * 4;                 // 16-B pieces per slab row (contiguous in HBM)
+    static constexpr int PIECES = SZ * SY * ROW_PIECES;
+};
+
+template <int KS, int BN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvSrcs s, const _Float16* __restrict__ wpk,
+                                                           int64_t wpk_bstride, const float* __restrict__ bias,
+                                                           float out_scale, float* __restrict__ out, Dims d,
+                                                           int cout, int total_chunks, int ntx, int nty, int nnb) {
+    using G = Geo<KS>;
+    constexpr int NJ = BN / 32;
+    constexpr int B_BYTES = 4 * BN * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsA = smem;
+    char* ldsB = smem + G::A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int V = d.D * d.H * d.W;
+
+    // XCD-aware remap: blocks id, id+8, ... share an XCD (round-robin dispatch); give each XCD a
+    // contiguous run of (tile, n-block) pairs so halo-sharing neighbours meet in one L2.
+    int id = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
+    const int nb = id % nnb;
+    const int tile = id / nnb;
+    const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+    const int x0 = tx * 16 - G::HALO, y0 = ty * 8 - G::HALO, z0 = tz * 2 - G::HALO;
+
+    floatx16 acc[2][NJ];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[f][j][i] = 0.f;
+
+    const _Float16* wbase = wpk + (int64_t)b * wpk_bstride + (int64_t)nb * BN * 8;
+    // B staging: piece p = q*BN + n  ->  LDS byte p*16 ; global ((step*4 + q)*cout + n)*8 halves
+    constexpr int BP = (4 * BN + 255) / 256;
+    uint4 breg[BP];
+    auto loadB = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            int p = tid + 256 * i;
+            if (4 * BN >= 256 * (i + 1) || p < 4 * BN) {
+                int q = p / BN, n = p % BN;
+                breg[i] = *reinterpret_cast<const uint4*>(wbase + ((int64_t)(step * 4 + q) * cout + n) * 8);
+            }
+        }
+    };
+    auto storeB = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            int p = tid + 256 * i;
+            if (4 * BN >= 256 * (i + 1) || p < 4 * BN)
+                *reinterpret_cast<uint4*>(ldsB + buf * B_BYTES + p * 16) = breg[i];
+        }
+    };
+
+    // per-lane LDS read bases (bytes)
+    const int lx = lane & 15, lzz = (lane >> 4) & 1, lh = lane >> 5;
+    const int a_base = (lh * G::PLANE + lzz * G::PZ + (2 * wave) * G::SX + lx) * 16;
+    const int b_base = (lh * BN + (lane & 31)) * 16;
+
+    const int nsteps = total_chunks * G::NT;
+    loadB(0);
+    storeB(0);
+
+    int gch = 0;
+    for (int si = 0; si < s.n; ++si) {
+        for (int ch = 0; ch < s.chunks[si]; ++ch, ++gch) {
+            // ---- stage the halo'd A slab of this 16-channel chunk ------------------------------
+            const _Float16* src =
+                s.p[si] + ((int64_t)b * s.chunks_total[si] + s.chunk_off[si] + ch) * (int64_t)V * 32;
+#pragma unroll
+            for (int i = 0; i < (G::PIECES + 255) / 256; ++i) {
+                int p = tid + 256 * i;
+                if (p < G::PIECES) {
+                    int row = p / G::ROW_PIECES, within = p - row * G::ROW_PIECES;
+                    int vx = within >> 2, q = within & 3;
+                    int vy = row % G::SY, vz = row / G::SY;
+                    int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if ((unsigned)gx < (unsigned)d.W && (unsigned)gy < (unsigned)d.H && (unsigned)gz < (unsigned)d.D)
+                        v = *reinterpret_cast<const uint4*>(src + ((int64_t)(gz * d.H + gy) * d.W + gx) * 32 + q * 8);
+                    *reinterpret_cast<uint4*>(ldsA + (q * G::PLANE + vz * G::PZ + vy * G::SX + vx) * 16) = v;
+                }
+            }
+            __syncthreads();
+            // ---- taps --------------------------------------------------------------------------
+#pragma unroll
+            for (int tap = 0; tap < G::NT; ++tap) {
+                const int g = gch * G::NT + tap;
+                const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+                if (g + 1 < nsteps) loadB(g + 1);
+                const char* Bb = ldsB + (g & 1) * B_BYTES;
+                half8 a[2][2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int kind = 0; kind < 2; ++kind)
+                        a[f][kind] = *reinterpret_cast<const half8*>(
+                            ldsA + a_base + (kind * 2 * G::PLANE + dz * G::PZ + (f + dy) * G::SX + dx) * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    half8 bh = *reinterpret_cast<const half8*>(Bb + b_base + (j * 32) * 16);
+                    half8 bl = *reinterpret_cast<const half8*>(Bb + b_base + (2 * BN + j * 32) * 16);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][1], bh, acc[f][j], 0, 0, 0);
+                        acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bl, acc[f][j], 0, 0, 0);
+                        acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bh, acc[f][j], 0, 0, 0);
+                    }
+                }
+                if (g + 1 < nsteps) storeB((g + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: out[b][voxel][n] = acc*out_scale + bias[n] ------------------------------------
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+    const int col = lane & 31, rhalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nb * BN + j * 32 + col;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int gy = ty * 8 + 2 * wave + f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (i & 3) + 8 * (i >> 2) + 4 * rhalf;
+                const int gx = tx * 16 + (r & 15), gz = tz * 2 + (r >> 4);
+                if (gx < d.W && gy < d.H && gz < d.D)
+                    out[((int64_t)b * V + (int64_t)(gz * d.H + gy) * d.W + gx) * cout + n] =
+                        acc[f][j][i] * out_scale + bv;
+            }
+        }
+    }
+}
+
+template <int KS, int BN>
+static void launch_conv_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
+                          float out_scale, float* out, int B, Dims d, int cout, hipStream_t st) {
+    using G = Geo<KS>;
+    int total = 0;
+    for (int i = 0; i < s.n; ++i) total += s.chunks[i];
+    int ntx = (d.W + 15) / 16, nty = (d.H + 7) / 8, ntz = (d.D + 1) / 2, nnb = cout / BN;
+    size_t lds = G::A_BYTES + 2 * 4 * BN * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KS, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(ntx * nty * ntz * nnb, B);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, BN>), grid, dim3(256), lds, st, s, wpk, wpk_bstride, bias, out_scale,
+                       out, d, cout, total, ntx, nty, nnb);
+}
+
+void launch_conv_mfma(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
+                      float out_scale, float* out, int B, Dims d, int cout, int ksize, int* /*errflag*/,
+                      hipStream_t st) {
+    // cout is always a multiple of 32 here (small heads go through launch_head_final)
+    if (ksize == 3) {
+        if (cout % 128 == 0) launch_conv_t<3, 128>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        else if (cout % 64 == 0) launch_conv_t<3, 64>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        else launch_conv_t<3, 32>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+    } else {
+        if (cout % 128 == 0) launch_conv_t<1, 128>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        else if (cout % 64 == 0) launch_conv_t<1, 64>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        else launch_conv_t<1, 32>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing: torch [Cout][Cin][k][k][k] f32 -> [B][chunk][tap][q][Cout][8] halves, q = kind*2+khalf.
+// Input channels are laid out as the concatenation of the conv's sources, each padded to 16.
+// ------------------------------------------------------------------------------------------------
+struct Segs { int c[MAX_SRC]; int cp[MAX_SRC]; int n; };
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int nt, Segs sg,
+                                    int total_chunks, const float* __restrict__ cin_scale, float mul,
+                                    _Float16* __restrict__ wpk, int64_t per_b) {
+    const int b = blockIdx.y;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [chunk][tap][q][n]
+    int64_t total = (int64_t)nt * total_chunks * 4 * cout;
+    if (e >= total) return;
+    int n = e % cout;
+    int q = (e / cout) & 3;
+    int tap = (e / ((int64_t)cout * 4)) % nt;
+    int gch = e / ((int64_t)cout * 4 * nt);
+    int kind = q >> 1, kh = q & 1;
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int kp = gch * 16 + kh * 8 + j;   // padded concat channel
+        int ci = -1, accp = 0, accc = 0;
+        for (int s = 0; s < sg.n; ++s) {
+            if (kp >= accp && kp < accp + sg.cp[s]) {
+                int local = kp - accp;
+                if (local < sg.c[s]) ci = accc + local;
+            }
+            accp += sg.cp[s];
+            accc += sg.c[s];
+        }
+        float v = 0.f;
+        if (ci >= 0) {
+            v = w[((int64_t)n * cin + ci) * nt + tap] * mul;
+            if (cin_scale) v *= cin_scale[(int64_t)b * cin + ci];
+        }
+        _Float16 hi = (_Float16)v;
+        _Float16 lo = (_Float16)(v - (float)hi);
+        o[j] = kind ? lo : hi;
+    }
+    *reinterpret_cast<half8*>(wpk + (int64_t)b * per_b + e * 8) = o;
+}
+
+int64_t packed_weight_halves(int cout, int ksize, int total_chunks) {
+    return (int64_t)ksize * ksize * ksize * total_chunks * 4 * cout * 8;
+}
+
+void launch_pack_weights(const float* w, int cout, int cin, int ksize, const int* h_seg_c, const int* h_seg_cp,
+                         int nseg, const float* cin_scale, int B, float cout_scale, float wscale, _Float16* wpk,
+                         hipStream_t st) {
+    Segs sg;
+    sg.n = nseg;
+    int total_chunks = 0;
+    for (int i = 0; i < nseg; ++i) {
+        sg.c[i] = h_seg_c[i];
+        sg.cp[i] = h_seg_cp[i];
+        total_chunks += h_seg_cp[i] / 16;
+    }
+    int nt = ksize * ksize * ksize;
+    int64_t total = (int64_t)nt * total_chunks * 4 * cout;
+    dim3 grid((unsigned)((total + 255) / 256), B);
+    hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, st, w, cout, cin, nt, sg, total_chunks, cin_scale,
+                       cout_scale * wscale, wpk, packed_weight_halves(cout, ksize, total_chunks));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise 3x3x3 (model.py:80) with the producer's InstanceNorm+ReLU and the SE gate applied on load:
+//   y = scale[c] * relu((x - mean[c]) * rstd[c]);  out = sum_tap w[tap][c] * y(shifted, zero padded) + bias
+// HBM-bound (8 B/voxel/channel algorithmic); the 27 shifted reads are served by L1/L2.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict__ x, Dims d, int C,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ scale, const float* __restrict__ w27,
+                                                        const float* __restrict__ bias, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int V = d.D * d.H * d.W;
+    const int c4n = C >> 2;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)V * c4n) return;
+    const int c = (int)(e % c4n) * 4;
+    const int v = (int)(e / c4n);
+    const int xw = v % d.W, yh = (v / d.W) % d.H, zd = v / (d.W * d.H);
+    float4 m = make_float4(0, 0, 0, 0), r = make_float4(1, 1, 1, 1), sc = make_float4(1, 1, 1, 1);
+    if (mean) { m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c); r = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c); }
+    if (scale) sc = *reinterpret_cast<const float4*>(scale + (int64_t)b * C + c);
+    float4 acc = *reinterpret_cast<const float4*>(bias + c);
+    const float* xb = x + (int64_t)b * V * C;
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                int zz = zd + dz, yy = yh + dy, xx = xw + dx;
+                if ((unsigned)zz < (unsigned)d.D && (unsigned)yy < (unsigned)d.H && (unsigned)xx < (unsigned)d.W) {
+                    float4 t = *reinterpret_cast<const float4*>(xb + ((int64_t)(zz * d.H + yy) * d.W + xx) * C + c);
+                    if (mean) {
+                        t.x = fmaxf((t.x - m.x) * r.x, 0.f) * sc.x; t.y = fmaxf((t.y - m.y) * r.y, 0.f) * sc.y;
+                        t.z = fmaxf((t.z - m.z) * r.z, 0.f) * sc.z; t.w = fmaxf((t.w - m.w) * r.w, 0.f) * sc.w;
+                    } else { t.x *= sc.x; t.y *= sc.y; t.z *= sc.z; t.w *= sc.w; }
+                    const int tap = ((dz + 1) * 3 + (dy + 1)) * 3 + (dx + 1);
+                    float4 wv = *reinterpret_cast<const float4*>(w27 + tap * C + c);
+                    acc.x = fmaf(wv.x, t.x, acc.x); acc.y = fmaf(wv.y, t.y, acc.y);
+                    acc.z = fmaf(wv.z, t.z, acc.z); acc.w = fmaf(wv.w, t.w, acc.w);
+                }
+            }
+    *reinterpret_cast<float4*>(out + ((int64_t)b * V + v) * C + c) = acc;
+}
+
+void launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
+                      const float* scale, const float* w27, const float* bias, float* out, hipStream_t st) {
+    int64_t n = (int64_t)d.D * d.H * d.W * (C / 4);
+    dim3 grid((unsigned)((n + 255) / 256), B);
+    hipLaunchKernelGGL(depthwise_kernel, grid, dim3(256), 0, st, x, d, C, mean, rstd, scale, w27, bias, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-scale stem (model.py:9-14,49-51): four Conv3d(1,32,k) with k = 3,5,7,9 on the density tile.
+// Cin = 1 leaves no GEMM K dimension, so this is f32 VALU work: one LDS tile with halo 4 serves all
+// four kernels; each thread keeps 2 voxels x 32 output channels in registers and the weights arrive
+// as wave-uniform scalar loads (v_fma with an SGPR operand).  Writes the 128 channels straight in
+// split format plus per-block channel sums for the attention gate's global average pool (model.py:21).
+// Workgroup tile: 32(x) x 8(y) x 2(z) voxels.
+// ------------------------------------------------------------------------------------------------
+constexpr int ST_X = 32, ST_Y = 8, ST_Z = 2, ST_H = 4;
+constexpr int ST_LX = ST_X + 2 * ST_H, ST_LY = ST_Y + 2 * ST_H, ST_LZ = ST_Z + 2 * ST_H;
+int64_t stem_weight_floats() { return (27 + 125 + 343 + 729) * 32; }
+
+template <int K>
+__device__ __forceinline__ void stem_one(const float* __restrict__ tile, const float* __restrict__ wc, int lx, int ly0,
+                                         int lz, float (&acc)[2][32]) {
+    constexpr int R = K / 2;
+    for (int dz = 0; dz < K; ++dz)
+        for (int dx = 0; dx < K; ++dx) {
+            float col[K + 1];
+            const float* p = tile + ((lz + dz + ST_H - R) * ST_LY + (ly0 + ST_H - R)) * ST_LX + (lx + dx + ST_H - R);
+#pragma unroll
+            for (int i = 0; i < K + 1; ++i) col[i] = p[i * ST_LX];
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy) {
+                const float* wt = wc + ((dz * K + dy) * K + dx) * 32;
+#pragma unroll
+                for (int co = 0; co < 32; ++co) {
+                    float wv = wt[co];
+                    acc[0][co] = fmaf(wv, col[dy], acc[0][co]);
+                    acc[1][co] = fmaf(wv, col[dy + 1], acc[1][co]);
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ map, Dims d,
+                                                   const float* __restrict__ wstem, const float* __restrict__ bstem,
+                                                   SplitView out, float* __restrict__ out_raw,
+                                                   float* __restrict__ ws, int ntx, int nty) {
+    __shared__ float tile[ST_LZ * ST_LY * ST_LX];
+    __shared__ float csum[4][128];   // per-wave partial channel sums (fixed summation order => deterministic)
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int V = d.D * d.H * d.W;
+    const int t = blockIdx.x;
+    const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+    const int x0 = tx * ST_X, y0 = ty * ST_Y, z0 = tz * ST_Z;
+    const float* mb = map + (int64_t)b * V;
+    for (int i = tid; i < ST_LZ * ST_LY * ST_LX; i += 256) {
+        int lx = i % ST_LX, ly = (i / ST_LX) % ST_LY, lz = i / (ST_LX * ST_LY);
+        int gx = x0 + lx - ST_H, gy = y0 + ly - ST_H, gz = z0 + lz - ST_H;
+        float v = 0.f;
+        if ((unsigned)gx < (unsigned)d.W && (unsigned)gy < (unsigned)d.H && (unsigned)gz < (unsigned)d.D)
+            v = mb[(int64_t)(gz * d.H + gy) * d.W + gx];
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int lx = tid & 31, ly0 = ((tid >> 5) & 3) * 2, lz = tid >> 7;
+    const int gx = x0 + lx, gz = z0 + lz;
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        float acc[2][32];
+#pragma unroll
+        for (int co = 0; co < 32; ++co) { acc[0][co] = bstem[c * 32 + co]; acc[1][co] = acc[0][co]; }
+        if (c == 0) stem_one<3>(tile, wstem, lx, ly0, lz, acc);
+        else if (c == 1) stem_one<5>(tile, wstem + 27 * 32, lx, ly0, lz, acc);
+        else if (c == 2) stem_one<7>(tile, wstem + (27 + 125) * 32, lx, ly0, lz, acc);
+        else stem_one<9>(tile, wstem + (27 + 125 + 343) * 32, lx, ly0, lz, acc);
+        float sums[32];
+#pragma unroll
+        for (int co = 0; co < 32; ++co) sums[co] = 0.f;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int gy = y0 + ly0 + v;
+            const bool ok = gx < d.W && gy < d.H && gz < d.D;
+            if (ok) {
+                const int64_t vox = (int64_t)(gz * d.H + gy) * d.W + gx;
+#pragma unroll
+                for (int co = 0; co < 32; ++co) sums[co] += acc[v][co];
+                if (out.p) {
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        half8 hi[2], lo[2];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            float xs = acc[v][cc * 16 + j] * ASCALE;
+                            _Float16 h = (_Float16)xs;
+                            hi[j >> 3][j & 7] = h;
+                            lo[j >> 3][j & 7] = (_Float16)(xs - (float)h);
+                        }
+                        _Float16* dst = out.p + (((int64_t)b * out.chunks_total + out.chunk_off + c * 2 + cc) * V + vox) * 32;
+                        *reinterpret_cast<half8*>(dst) = hi[0];
+                        *reinterpret_cast<half8*>(dst + 8) = hi[1];
+                        *reinterpret_cast<half8*>(dst + 16) = lo[0];
+                        *reinterpret_cast<half8*>(dst + 24) = lo[1];
+                    }
+                }
+                if (out_raw) {
+                    float* dr = out_raw + ((int64_t)b * V + vox) * 128 + c * 32;
+#pragma unroll
+                    for (int co = 0; co < 32; co += 4)
+                        *reinterpret_cast<float4*>(dr + co) = make_float4(acc[v][co], acc[v][co + 1], acc[v][co + 2], acc[v][co + 3]);
+                }
+            }
+        }
+        // block partial channel sums (wave shuffle reduce, then LDS)
+#pragma unroll
+        for (int co = 0; co < 32; ++co) {
+            float sv = sums[co];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+            if ((tid & 63) == 0) csum[tid >> 6][c * 32 + co] = sv;
+        }
+    }
+    __syncthreads();
+    if (ws && tid < 128)
+        ws[((int64_t)b * gridDim.x + blockIdx.x) * 128 + tid] = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
+}
+
+void launch_stem(const float* map, int B, Dims d, const float* wstem, const float* bstem, SplitView out,
+                 float* out_raw, float* gap, float* ws, hipStream_t st) {
+    int ntx = (d.W + ST_X - 1) / ST_X, nty = (d.H + ST_Y - 1) / ST_Y, ntz = (d.D + ST_Z - 1) / ST_Z;
+    dim3 grid(ntx * nty * ntz, B);
+    hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, st, map, d, wstem, bstem, out, out_raw, gap ? ws : nullptr, ntx, nty);
+    if (gap) launch_finalize_sum(ws, B, (int)grid.x, 128, 1.0f / (float)(d.D * d.H * d.W), gap, st);
+}
+
+}  // namespace mica

@@ -1,0 +1,527 @@
+// HBM-bound streaming kernels of the MICA hot path: InstanceNorm statistics and apply(+ReLU, +gate)
+// with the split-f16 re-encoding the MFMA conv consumes, squeeze-excite style gate MLPs, head tails,
+// softmax/argmax post-processing, tile gather and stitch.  All f32 arithmetic; one pass over the data each.
+#include "common.h"
+
+namespace mica {
+
+static inline int pick_blocks(int V, int vox_per_iter, int cap) {
+    int nb = (V + vox_per_iter - 1) / vox_per_iter;
+    return nb < cap ? (nb < 1 ? 1 : nb) : cap;
+}
+constexpr int RED_BLOCKS = 1024;   // max partial blocks per batch entry for reductions
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm3d statistics (model.py:81,108,116,123,143,211,213): per (tile, channel) mean and biased
+// variance over all V voxels, eps = 1e-5.  Thread = (8-channel group g, voxel lane); shifted sums per
+// thread, Chan merges inside the block (f32) and across blocks (f64, fixed order => deterministic).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+    float n = na + nb;
+    if (nb > 0.f) {
+        if (na == 0.f) { na = nb; ma = mb; qa = qb; return; }
+        float dlt = mb - ma;
+        ma = ma + dlt * (nb / n);
+        qa = qa + qb + dlt * dlt * (na * nb / n);
+        na = n;
+    }
+}
+
+__global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x, int V, int C, float* __restrict__ ws) {
+    extern __shared__ float sh[];   // [3][256][8]
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int G = C >> 3, SUB = 256 / G;
+    const int tid = threadIdx.x, g = tid % G, sub = tid / G;
+    const int per = (V + nblk - 1) / nblk;
+    const int v0 = blk * per, v1 = min(V, v0 + per);
+    float K[8], s[8], q[8];
+    float n = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { K[j] = 0.f; s[j] = 0.f; q[j] = 0.f; }
+    const float* xb = x + (int64_t)b * V * C + g * 8;
+    for (int v = v0 + sub; v < v1; v += SUB) {
+        float4 a = *reinterpret_cast<const float4*>(xb + (int64_t)v * C);
+        float4 c = *reinterpret_cast<const float4*>(xb + (int64_t)v * C + 4);
+        float val[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        if (n == 0.f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) K[j] = val[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float t = val[j] - K[j]; s[j] += t; q[j] = fmaf(t, t, q[j]); }
+        n += 1.f;
+    }
+    float* shn = sh; float* shm = sh + 256 * 8; float* shq = sh + 2 * 256 * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float mean = 0.f, m2 = 0.f;
+        if (n > 0.f) { mean = K[j] + s[j] / n; m2 = fmaxf(q[j] - s[j] * s[j] / n, 0.f); }
+        shn[tid * 8 + j] = n; shm[tid * 8 + j] = mean; shq[tid * 8 + j] = m2;
+    }
+    __syncthreads();
+    for (int off = SUB >> 1; off > 0; off >>= 1) {
+        if (sub < off) {
+            const int o = (sub + off) * G + g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float na = shn[tid * 8 + j], ma = shm[tid * 8 + j], qa = shq[tid * 8 + j];
+                chan_merge(na, ma, qa, shn[o * 8 + j], shm[o * 8 + j], shq[o * 8 + j]);
+                shn[tid * 8 + j] = na; shm[tid * 8 + j] = ma; shq[tid * 8 + j] = qa;
+            }
+        }
+        __syncthreads();
+    }
+    if (sub == 0) {
+        float* w = ws + (((int64_t)b * nblk + blk) * C + g * 8) * 3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { w[j * 3] = shn[tid * 8 + j]; w[j * 3 + 1] = shm[tid * 8 + j]; w[j * 3 + 2] = shq[tid * 8 + j]; }
+    }
+}
+
+__global__ void stats_finalize_kernel(const float* __restrict__ ws, int nblk, int C, float eps,
+                                      float* __restrict__ mean, float* __restrict__ rstd) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double n = 0, m = 0, q = 0;
+        for (int k = 0; k < nblk; ++k) {
+            const float* w = ws + (((int64_t)b * nblk + k) * C + c) * 3;
+            double nb = w[0], mb = w[1], qb = w[2];
+            if (nb > 0) {
+                double nn = n + nb, dl = mb - m;
+                m += dl * (nb / nn);
+                q += qb + dl * dl * (n * nb / nn);
+                n = nn;
+            }
+        }
+        mean[(int64_t)b * C + c] = (float)m;
+        rstd[(int64_t)b * C + c] = (float)(1.0 / sqrt(q / n + (double)eps));
+    }
+}
+
+int64_t stats_ws_floats(int B, int C) { return (int64_t)B * RED_BLOCKS * C * 3; }
+
+void launch_stats(const float* x, int B, int V, int C, float eps, float* mean, float* rstd, float* ws, hipStream_t st) {
+    int G = C / 8, SUB = 256 / G;
+    int nblk = pick_blocks(V, SUB * 8, RED_BLOCKS);
+    hipLaunchKernelGGL(stats_kernel, dim3(nblk, B), dim3(256), 3 * 256 * 8 * sizeof(float), st, x, V, C, ws);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd);
+}
+
+__global__ void finalize_sum_kernel(const float* __restrict__ ws, int nblocks, int C, float inv, float* __restrict__ out) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0.0;
+        for (int k = 0; k < nblocks; ++k) s += (double)ws[((int64_t)b * nblocks + k) * C + c];
+        out[(int64_t)b * C + c] = (float)(s * inv);
+    }
+}
+void launch_finalize_sum(const float* ws, int B, int nblocks, int C, float inv, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3(B), dim3(256), 0, st, ws, nblocks, C, inv, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: y = relu?((x - mean) * rstd) * scale  ->  split view (the next conv's operand), optional raw
+// copy, optional global-average-pool of y (SE / calibration gates, model.py:216,244).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const float (&y)[8], half8& hi, half8& lo, bool& bad) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float xs = y[j] * ASCALE;
+        bad |= !(fabsf(xs) <= F16_LIMIT);
+        _Float16 h = (_Float16)xs;
+        hi[j] = h;
+        lo[j] = (_Float16)(xs - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, int V, int C,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   int relu, const float* __restrict__ scale, SplitView out,
+                                                   float* __restrict__ out_raw, float* __restrict__ ws,
+                                                   int* __restrict__ errflag) {
+    extern __shared__ float sh[];   // [256][8] for the gap reduction
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int G = C >> 3, SUB = 256 / G;
+    const int tid = threadIdx.x, g = tid % G, sub = tid / G;
+    const int per = (V + nblk - 1) / nblk;
+    const int v0 = blk * per, v1 = min(V, v0 + per);
+    float m[8], r[8], sc[8], acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t ci = (int64_t)b * C + g * 8 + j;
+        m[j] = mean ? mean[ci] : 0.f;
+        r[j] = rstd ? rstd[ci] : 1.f;
+        sc[j] = scale ? scale[ci] : 1.f;
+        acc[j] = 0.f;
+    }
+    bool bad = false;
+    const float* xb = x + (int64_t)b * V * C + g * 8;
+    _Float16* ob = out.p ? out.p + (((int64_t)b * out.chunks_total + out.chunk_off + (g >> 1)) * V) * 32 + (g & 1) * 8 : nullptr;
+    for (int v = v0 + sub; v < v1; v += SUB) {
+        float4 a = *reinterpret_cast<const float4*>(xb + (int64_t)v * C);
+        float4 c = *reinterpret_cast<const float4*>(xb + (int64_t)v * C + 4);
+        float y[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = (y[j] - m[j]) * r[j];
+            if (relu) t = fmaxf(t, 0.f);
+            y[j] = t * sc[j];
+            acc[j] += y[j];
+        }
+        if (out_raw) {
+            float* o = out_raw + ((int64_t)b * V + v) * C + g * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+        if (ob) {
+            half8 hi, lo;
+            split8(y, hi, lo, bad);
+            *reinterpret_cast<half8*>(ob + (int64_t)v * 32) = hi;
+            *reinterpret_cast<half8*>(ob + (int64_t)v * 32 + 16) = lo;
+        }
+    }
+    if (bad) atomicOr(errflag, 1);
+    if (ws) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[tid * 8 + j] = acc[j];
+        __syncthreads();
+        for (int off = SUB >> 1; off > 0; off >>= 1) {
+            if (sub < off) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sh[tid * 8 + j] += sh[((sub + off) * G + g) * 8 + j];
+            }
+            __syncthreads();
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ws[((int64_t)b * nblk + blk) * C + g * 8 + j] = sh[tid * 8 + j];
+        }
+    }
+}
+
+void launch_prep(const float* x, int B, int V, int C, const float* mean, const float* rstd, int relu,
+                 const float* scale, SplitView out, float* out_raw, float* gap, float* ws, int* errflag,
+                 hipStream_t st) {
+    int G = C / 8, SUB = 256 / G;
+    int nblk = pick_blocks(V, SUB * 4, gap ? RED_BLOCKS : 4096);
+    hipLaunchKernelGGL(prep_kernel, dim3(nblk, B), dim3(256), 256 * 8 * sizeof(float), st, x, V, C, mean, rstd, relu,
+                       scale, out, out_raw, gap ? ws : nullptr, errflag);
+    if (gap) launch_finalize_sum(ws, B, nblk, C, 1.0f / (float)V, gap, st);
+}
+
+// NCDHW f32 [B][C][V] (the caller's layout, model.py:331) -> split, channels zero-padded to 16.
+__global__ __launch_bounds__(256) void prep_ncdhw_kernel(const float* __restrict__ x, int V, int C, SplitView out,
+                                                         float* __restrict__ abs_sum, int* __restrict__ errflag) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    float asum = 0.f;
+    bool bad = false;
+    if (v < V) {
+        float y[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int c = ch * 16 + j;
+            y[j] = c < C ? x[((int64_t)b * C + c) * V + v] : 0.f;
+            asum += fabsf(y[j]);
+        }
+        if (out.p) {
+            _Float16* o = out.p + (((int64_t)b * out.chunks_total + out.chunk_off + ch) * V + v) * 32;
+            half8 hi, lo;
+            float y0[8], y1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { y0[j] = y[j]; y1[j] = y[8 + j]; }
+            split8(y0, hi, lo, bad);
+            *reinterpret_cast<half8*>(o) = hi;
+            *reinterpret_cast<half8*>(o + 16) = lo;
+            split8(y1, hi, lo, bad);
+            *reinterpret_cast<half8*>(o + 8) = hi;
+            *reinterpret_cast<half8*>(o + 24) = lo;
+        }
+    }
+    if (bad) atomicOr(errflag, 1);
+    if (abs_sum) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) asum += __shfl_xor(asum, o);
+        if ((threadIdx.x & 63) == 0 && asum != 0.f) atomicAdd(abs_sum + b, asum);
+    }
+}
+
+void launch_prep_ncdhw(const float* x, int B, int V, int C, SplitView out, float* abs_sum, int* errflag, hipStream_t st) {
+    dim3 grid((V + 255) / 256, (C + 15) / 16, B);
+    hipLaunchKernelGGL(prep_ncdhw_kernel, grid, dim3(256), 0, st, x, V, C, out, abs_sum, errflag);
+}
+
+// layout transposes for the op-level entry points (tests): tiled through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int R, int Cc, float* __restrict__ y) {
+    // x [batch][R][Cc] -> y [batch][Cc][R]
+    __shared__ float t[32][33];
+    const int b = blockIdx.z;
+    const float* xb = x + (int64_t)b * R * Cc;
+    float* yb = y + (int64_t)b * R * Cc;
+    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        int r = r0 + i, c = c0 + tx;
+        if (r < R && c < Cc) t[i][tx] = xb[(int64_t)r * Cc + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, r = r0 + tx;
+        if (r < R && c < Cc) yb[(int64_t)c * R + r] = t[tx][i];
+    }
+}
+void launch_nchw_to_nhwc(const float* x, int B, int C, int V, float* y, hipStream_t st) {
+    dim3 grid((V + 31) / 32, (C + 31) / 32, B);   // x [B][C][V] : R = C, Cc = V
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, x, C, V, y);
+}
+void launch_nhwc_to_nchw(const float* x, int B, int C, int V, float* y, hipStream_t st) {
+    dim3 grid((C + 31) / 32, (V + 31) / 32, B);   // x [B][V][C] : R = V, Cc = C
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, x, V, C, y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gate MLPs: SEBlock.fc (model.py:245-258), exp_attention (:20-26), global_attn (:87-94),
+// calibration (:215-223): gate = sigmoid(W2 relu(W1 p + b1) + b2), p = pooled vector (* premul).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_mlp_kernel(const float* __restrict__ pool, const float* __restrict__ premul,
+                                                       int C, int Ch, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       const float* __restrict__ postmul, float* __restrict__ gate,
+                                                       float* __restrict__ gate_post, int post_stride) {
+    __shared__ float p[512];
+    __shared__ float hid[128];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) p[c] = pool[(int64_t)b * C + c] * (premul ? premul[(int64_t)b * C + c] : 1.f);
+    __syncthreads();
+    for (int h = tid; h < Ch; h += 256) {
+        float s = b1[h];
+        for (int c = 0; c < C; ++c) s = fmaf(w1[(int64_t)h * C + c], p[c], s);
+        hid[h] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = b2[c];
+        for (int h = 0; h < Ch; ++h) s = fmaf(w2[(int64_t)c * Ch + h], hid[h], s);
+        float gv = 1.f / (1.f + expf(-s));
+        if (gate) gate[(int64_t)b * C + c] = gv;
+        if (gate_post) gate_post[(int64_t)b * post_stride + c] = gv * (postmul ? postmul[(int64_t)b * C + c] : 1.f);
+    }
+}
+void launch_gate_mlp(const float* pool, const float* premul, int B, int C, int Ch, const float* w1, const float* b1,
+                     const float* w2, const float* b2, const float* postmul, float* gate, float* gate_post, int post_stride,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(gate_mlp_kernel, dim3(B), dim3(256), 0, st, pool, premul, C, Ch, w1, b1, w2, b2, postmul, gate,
+                       gate_post, post_stride);
+}
+
+// ------------------------------------------------------------------------------------------------
+// feat_gate (model.py:31-36,70-71): per-voxel importance = sigmoid(w2 . relu(W0 x + b0) + b2), x*importance
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void feat_gate_kernel(const float* __restrict__ x, int V, const float* __restrict__ w0,
+                                                        const float* __restrict__ b0, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, SplitView out, int* __restrict__ errflag) {
+    __shared__ float sw0[16 * 64];
+    __shared__ float sb0[16], sw2[16];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < 16 * 64; i += 256) sw0[i] = w0[i];
+    if (tid < 16) { sb0[tid] = b0[tid]; sw2[tid] = w2[tid]; }
+    __syncthreads();
+    const int v = blockIdx.x * 256 + tid;
+    if (v >= V) return;
+    float xv[64];
+    const float* xp = x + ((int64_t)b * V + v) * 64;
+#pragma unroll
+    for (int j = 0; j < 64; j += 4) {
+        float4 a = *reinterpret_cast<const float4*>(xp + j);
+        xv[j] = a.x; xv[j + 1] = a.y; xv[j + 2] = a.z; xv[j + 3] = a.w;
+    }
+    float z = b2[0];
+#pragma unroll 1
+    for (int h = 0; h < 16; ++h) {
+        float s = sb0[h];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) s = fmaf(sw0[h * 64 + j], xv[j], s);
+        z = fmaf(sw2[h], fmaxf(s, 0.f), z);
+    }
+    const float gt = 1.f / (1.f + expf(-z));
+    bool bad = false;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        _Float16* o = out.p + (((int64_t)b * out.chunks_total + out.chunk_off + ch) * V + v) * 32;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = xv[ch * 16 + kh * 8 + j] * gt;
+            half8 hi, lo;
+            split8(y, hi, lo, bad);
+            *reinterpret_cast<half8*>(o + kh * 8) = hi;
+            *reinterpret_cast<half8*>(o + 16 + kh * 8) = lo;
+        }
+    }
+    if (bad) atomicOr(errflag, 1);
+}
+void launch_feat_gate(const float* x, int B, int V, const float* w0, const float* b0, const float* w2, const float* b2,
+                      SplitView out, int* errflag, hipStream_t st) {
+    hipLaunchKernelGGL(feat_gate_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, x, V, w0, b0, w2, b2, out, errflag);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head tail (model.py:232,238-239): relu(IN(conv2 out)) * calibration gate -> final 1x1 (32 -> ncls).
+// Writes NCDHW logits (the inner boundary's layout) and, for the backbone / CA heads, the logits as
+// extra input channels of the next head's conv1 (model.py:345-346).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict__ x, int V, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gate,
+                                                         const float* __restrict__ wf, const float* __restrict__ bf, int ncls,
+                                                         float* __restrict__ logits, SplitView extra, int extra_off) {
+    __shared__ float sw[21 * 32];
+    __shared__ float sm[32], sr[32], sg[32], sb[21];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < ncls * 32; i += 256) sw[i] = wf[i];
+    if (tid < 32) { sm[tid] = mean[(int64_t)b * 32 + tid]; sr[tid] = rstd[(int64_t)b * 32 + tid]; sg[tid] = gate[(int64_t)b * 32 + tid]; }
+    if (tid < ncls) sb[tid] = bf[tid];
+    __syncthreads();
+    const int v = blockIdx.x * 256 + tid;
+    if (v >= V) return;
+    float t[32];
+    const float* xp = x + ((int64_t)b * V + v) * 32;
+#pragma unroll
+    for (int j = 0; j < 32; j += 4) {
+        float4 a = *reinterpret_cast<const float4*>(xp + j);
+        t[j] = a.x; t[j + 1] = a.y; t[j + 2] = a.z; t[j + 3] = a.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) t[j] = fmaxf((t[j] - sm[j]) * sr[j], 0.f) * sg[j];
+    _Float16* eo = extra.p ? extra.p + (((int64_t)b * extra.chunks_total + extra.chunk_off) * V + v) * 32 : nullptr;
+    for (int n = 0; n < ncls; ++n) {
+        float s = sb[n];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s = fmaf(sw[n * 32 + j], t[j], s);
+        logits[((int64_t)b * ncls + n) * V + v] = s;
+        if (eo) {
+            float xs = s * ASCALE;
+            _Float16 h = (_Float16)xs;
+            eo[extra_off + n] = h;
+            eo[16 + extra_off + n] = (_Float16)(xs - (float)h);
+        }
+    }
+}
+void launch_head_final(const float* x, int B, int V, const float* mean, const float* rstd, const float* gate,
+                       const float* wf, const float* bf, int ncls, float* logits, SplitView extra, int extra_ch_off,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(head_final_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, x, V, mean, rstd, gate, wf, bf,
+                       ncls, logits, extra, extra_ch_off);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head post-processing (utils/predict.py:342-349): class 1 dropped, softmax over the remaining three,
+// keep the last; amino acids: softmax over classes 1..20 and argmax (first maximum).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softmax3_last(float a, float c, float e) {
+    float m = fmaxf(a, fmaxf(c, e));
+    float ea = expf(a - m), ec = expf(c - m), ee = expf(e - m);
+    return ee / (ea + ec + ee);
+}
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ bb, const float* __restrict__ ca,
+                                                          const float* __restrict__ aa, int V, float* __restrict__ bbp,
+                                                          float* __restrict__ cap, float* __restrict__ aap,
+                                                          float* __restrict__ aapred) {
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float* pb = bb + (int64_t)b * 4 * V + v;
+    const float* pc = ca + (int64_t)b * 4 * V + v;
+    bbp[(int64_t)b * V + v] = softmax3_last(pb[0], pb[2 * (int64_t)V], pb[3 * (int64_t)V]);
+    cap[(int64_t)b * V + v] = softmax3_last(pc[0], pc[2 * (int64_t)V], pc[3 * (int64_t)V]);
+    const float* pa = aa + (int64_t)b * 21 * V + v;
+    float l[20];
+    float m = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int j = 0; j < 20; ++j) {
+        l[j] = pa[(int64_t)(j + 1) * V];
+        if (l[j] > m) { m = l[j]; am = j; }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 20; ++j) { l[j] = expf(l[j] - m); s += l[j]; }
+#pragma unroll
+    for (int j = 0; j < 20; ++j) aap[((int64_t)b * 20 + j) * V + v] = l[j] / s;
+    aapred[(int64_t)b * V + v] = (float)am;
+}
+void launch_postprocess(const float* bb, const float* ca, const float* aa, int B, int V, float* bbp, float* cap,
+                        float* aap, float* aapred, hipStream_t st) {
+    hipLaunchKernelGGL(postprocess_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, bb, ca, aa, V, bbp, cap, aap, aapred);
+}
+
+__global__ void fill_float_kernel(float* p, int64_t n, float v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill_float(float* p, int64_t n, float v, hipStream_t st) {
+    hipLaunchKernelGGL(fill_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+}
+__global__ void fill_half_kernel(_Float16* p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (_Float16)0.f;
+}
+void launch_fill_half(_Float16* p, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(fill_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile gather (create_grids.py:129-157): window W = grid + 2*pad at stride grid from the zero-padded
+// volume; out-of-volume voxels read 0 (np.pad 'constant').  Pure copy => bit exact.
+// Stitch (predict.py:494-501): central grid^3 of every tile back into the volume; regions are disjoint.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_tiles_kernel(const float* __restrict__ vol, int C, int64_t n0, int64_t n1,
+                                                           int64_t n2, int grid, int pad, int64_t first, int nt1, int nt2,
+                                                           float* __restrict__ tiles) {
+    const int W = grid + 2 * pad;
+    const int64_t W3 = (int64_t)W * W * W;
+    const int t = blockIdx.z, c = blockIdx.y;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= W3) return;
+    const int a2 = e % W, a1 = (e / W) % W, a0 = e / ((int64_t)W * W);
+    const int64_t tg = first + t;
+    const int64_t tk = tg % nt2, tj = (tg / nt2) % nt1, ti = tg / ((int64_t)nt2 * nt1);
+    const int64_t s0 = ti * grid + a0 - pad, s1 = tj * grid + a1 - pad, s2 = tk * grid + a2 - pad;
+    float v = 0.f;
+    if (s0 >= 0 && s0 < n0 && s1 >= 0 && s1 < n1 && s2 >= 0 && s2 < n2) v = vol[(((int64_t)c * n0 + s0) * n1 + s1) * n2 + s2];
+    tiles[((int64_t)t * C + c) * W3 + e] = v;
+}
+void launch_gather_tiles(const float* vol, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad, int64_t first,
+                         int64_t count, float* tiles, hipStream_t st) {
+    int W = grid + 2 * pad;
+    int64_t W3 = (int64_t)W * W * W;
+    int nt1 = (int)((n1 + grid - 1) / grid), nt2 = (int)((n2 + grid - 1) / grid);
+    dim3 g((unsigned)((W3 + 255) / 256), C, (unsigned)count);
+    hipLaunchKernelGGL(gather_tiles_kernel, g, dim3(256), 0, st, vol, C, n0, n1, n2, grid, pad, first, nt1, nt2, tiles);
+}
+
+__global__ __launch_bounds__(256) void stitch_tiles_kernel(const float* __restrict__ tiles, int C, int64_t n0, int64_t n1,
+                                                           int64_t n2, int grid, int pad, int64_t first, int nt1, int nt2,
+                                                           float* __restrict__ vol) {
+    const int W = grid + 2 * pad;
+    const int64_t W3 = (int64_t)W * W * W, G3 = (int64_t)grid * grid * grid;
+    const int t = blockIdx.z, c = blockIdx.y;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= G3) return;
+    const int u2 = e % grid, u1 = (e / grid) % grid, u0 = e / ((int64_t)grid * grid);
+    const int64_t tg = first + t;
+    const int64_t tk = tg % nt2, tj = (tg / nt2) % nt1, ti = tg / ((int64_t)nt2 * nt1);
+    const int64_t d0 = ti * grid + u0, d1 = tj * grid + u1, d2 = tk * grid + u2;
+    if (d0 < n0 && d1 < n1 && d2 < n2)
+        vol[(((int64_t)c * n0 + d0) * n1 + d1) * n2 + d2] =
+            tiles[((int64_t)t * C + c) * W3 + ((int64_t)(pad + u0) * W + (pad + u1)) * W + (pad + u2)];
+}
+void launch_stitch_tiles(const float* tiles, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad, int64_t first,
+                         int64_t count, float* vol, hipStream_t st) {
+    int64_t G3 = (int64_t)grid * grid * grid;
+    int nt1 = (int)((n1 + grid - 1) / grid), nt2 = (int)((n2 + grid - 1) / grid);
+    dim3 g((unsigned)((G3 + 255) / 256), C, (unsigned)count);
+    hipLaunchKernelGGL(stitch_tiles_kernel, g, dim3(256), 0, st, tiles, C, n0, n1, n2, grid, pad, first, nt1, nt2, vol);
+}
+
+}  // namespace mica

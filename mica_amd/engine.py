@@ -1,0 +1,208 @@
+"""Thin object wrapper over the C ABI: one Engine = one mica_ctx = one GPU.
+
+PyTorch is used for device memory and streams only (tensor.data_ptr() is what crosses the ABI)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _cabi
+from ._cabi import MicaHipError, AF_NONE, AF_PER_TILE, AF_BATCH  # noqa: F401
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise MicaHipError(f"{name}: expected a float32 CUDA(HIP) tensor, got {t.dtype} on {t.device}")
+    return t.contiguous()
+
+
+class Engine:
+    def __init__(self, device: int | str | torch.device = 0, max_batch: int = 1, tile_size: int = 64):
+        if not torch.cuda.is_available():
+            raise MicaHipError("no HIP device visible: mica_amd runs on MI355X (gfx950) only, there is no CPU fallback")
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if dev.type != "cuda":
+            raise MicaHipError(f"device {device!r} is not a GPU; mica_amd has no CPU path")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.lib = _cabi.load_library()
+        self.max_batch, self.tile_size = int(max_batch), int(tile_size)
+        h = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        r = self.lib.mica_create(self.device.index, self.max_batch, self.tile_size, C.byref(h))
+        if r != 0:
+            raise MicaHipError(f"mica_create failed ({r}): {self.lib.mica_last_error(None).decode()}")
+        self._h = h
+        self.weights_loaded = False
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _check(self, r, what):
+        if r != 0:
+            raise MicaHipError(f"{what} failed ({r}): {self.lib.mica_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mica_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mica_workspace_bytes(self._h))
+
+    # -- weights ----------------------------------------------------------------------------------
+    def load_state_dict(self, sd):
+        """sd: {name: float32 array/tensor} (125 tensors, optional 'module.' prefix)."""
+        for k, v in sd.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(self.lib.mica_load_weight(self._h, k.encode(), a.ctypes.data_as(_cabi._FP), shape, a.ndim),
+                        f"mica_load_weight({k})")
+        self._check(self.lib.mica_finalize_weights(self._h), "mica_finalize_weights")
+        self.weights_loaded = True
+
+    # -- forward ----------------------------------------------------------------------------------
+    def forward_logits(self, exp_map: torch.Tensor, af: torch.Tensor | None, af_mode: int = AF_BATCH):
+        S = self.tile_size
+        exp_map = _f32c(exp_map, "exp_map")
+        B = exp_map.shape[0]
+        if tuple(exp_map.shape) != (B, 1, S, S, S):
+            raise MicaHipError(f"exp_map must be [B,1,{S},{S},{S}], got {tuple(exp_map.shape)}")
+        if af is not None:
+            af = _f32c(af, "af_features")
+            if tuple(af.shape) != (B, 24, S, S, S):
+                raise MicaHipError(f"af_features must be [B,24,{S},{S},{S}], got {tuple(af.shape)}")
+        bb = torch.empty((B, 4, S, S, S), dtype=torch.float32, device=self.device)
+        ca = torch.empty_like(bb)
+        aa = torch.empty((B, 21, S, S, S), dtype=torch.float32, device=self.device)
+        for b0 in range(0, B, self.max_batch):
+            b1 = min(B, b0 + self.max_batch)
+            self._check(self.lib.mica_forward_logits(
+                self._h, _ptr(exp_map[b0:b1]), _ptr(af[b0:b1]) if af is not None else None, b1 - b0,
+                af_mode if af is not None else AF_NONE, _ptr(bb[b0:b1]), _ptr(ca[b0:b1]), _ptr(aa[b0:b1]), _stream()),
+                "mica_forward_logits")
+        return bb, ca, aa
+
+    def forward_tiles(self, map_tiles: torch.Tensor, af_tiles: torch.Tensor | None, out=None, af_mode: int = AF_PER_TILE):
+        """map_tiles f32[T,S^3-shaped], af_tiles f32[T,24,...] or None -> (bb_prob[T,S,S,S], ca_prob, aa_prob[T,20,S,S,S], aa_pred)."""
+        S = self.tile_size
+        T = map_tiles.shape[0]
+        map_tiles = _f32c(map_tiles, "map_tiles").view(T, 1, S, S, S)
+        if af_tiles is not None:
+            af_tiles = _f32c(af_tiles, "af_tiles").view(T, 24, S, S, S)
+        if out is None:
+            out = (torch.empty((T, S, S, S), dtype=torch.float32, device=self.device),
+                   torch.empty((T, S, S, S), dtype=torch.float32, device=self.device),
+                   torch.empty((T, 20, S, S, S), dtype=torch.float32, device=self.device),
+                   torch.empty((T, S, S, S), dtype=torch.float32, device=self.device))
+        bbp, cap, aap, pred = out
+        for b0 in range(0, T, self.max_batch):
+            b1 = min(T, b0 + self.max_batch)
+            self._check(self.lib.mica_forward_tiles(
+                self._h, _ptr(map_tiles[b0:b1]), _ptr(af_tiles[b0:b1]) if af_tiles is not None else None, b1 - b0,
+                af_mode if af_tiles is not None else AF_NONE, _ptr(bbp[b0:b1]), _ptr(cap[b0:b1]), _ptr(aap[b0:b1]),
+                _ptr(pred[b0:b1]), _stream()), "mica_forward_tiles")
+        return out
+
+    def postprocess(self, bb, ca, aa):
+        B = bb.shape[0]
+        S = self.tile_size
+        bb, ca, aa = _f32c(bb, "bb"), _f32c(ca, "ca"), _f32c(aa, "aa")
+        o = (torch.empty((B, S, S, S), dtype=torch.float32, device=self.device),
+             torch.empty((B, S, S, S), dtype=torch.float32, device=self.device),
+             torch.empty((B, 20, S, S, S), dtype=torch.float32, device=self.device),
+             torch.empty((B, S, S, S), dtype=torch.float32, device=self.device))
+        self._check(self.lib.mica_postprocess(self._h, _ptr(bb), _ptr(ca), _ptr(aa), B, *[_ptr(t) for t in o], _stream()),
+                    "mica_postprocess")
+        return o
+
+    # -- tiler / stitch / normalise -------------------------------------------------------------------
+    def gather_tiles(self, vol: torch.Tensor, grid: int, pad: int, first: int, count: int, out=None):
+        """vol f32[C,N0,N1,N2] (or [N0,N1,N2]) -> tiles f32[count,C,W,W,W]."""
+        vol = _f32c(vol, "vol")
+        if vol.dim() == 3:
+            vol = vol[None]
+        Cc, n0, n1, n2 = vol.shape
+        W = grid + 2 * pad
+        if out is None:
+            out = torch.empty((count, Cc, W, W, W), dtype=torch.float32, device=self.device)
+        self._check(self.lib.mica_gather_tiles(self._h, _ptr(vol), Cc, n0, n1, n2, grid, pad, first, count, _ptr(out), _stream()),
+                    "mica_gather_tiles")
+        return out
+
+    def stitch_tiles(self, tiles: torch.Tensor, vol: torch.Tensor, grid: int, pad: int, first: int):
+        """tiles f32[count,C,W,W,W] -> central regions into vol f32[C,N0,N1,N2] (in place)."""
+        tiles = _f32c(tiles, "tiles")
+        if not vol.is_contiguous():
+            raise MicaHipError("vol must be contiguous")
+        v4 = vol if vol.dim() == 4 else vol[None]
+        Cc, n0, n1, n2 = v4.shape
+        self._check(self.lib.mica_stitch_tiles(self._h, _ptr(tiles), Cc, n0, n1, n2, grid, pad, first, tiles.shape[0],
+                                               _ptr(v4), _stream()), "mica_stitch_tiles")
+        return vol
+
+    def normalise_map_(self, vol: torch.Tensor):
+        """In place; returns (median, percentile).  Raises MicaHipError like the reference logs failure."""
+        vol = _f32c(vol, "vol")
+        st = (C.c_double * 2)()
+        self._check(self.lib.mica_normalise_map(self._h, _ptr(vol), vol.numel(), st, _stream()), "mica_normalise_map")
+        return float(st[0]), float(st[1])
+
+    # -- single ops (tests) -----------------------------------------------------------------------------
+    def op_conv3d(self, x, w, b, k):
+        x = _f32c(x, "x")
+        B, cin, d, h, ww = x.shape
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        cout = w.shape[0]
+        y = torch.empty((B, cout, d, h, ww), dtype=torch.float32, device=self.device)
+        self._check(self.lib.mica_op_conv3d(self._h, _ptr(x), B, cin, d, h, ww, w.ctypes.data_as(_cabi._FP),
+                                            b.ctypes.data_as(_cabi._FP), cout, k, _ptr(y), _stream()), "mica_op_conv3d")
+        return y
+
+    def op_instnorm_relu(self, x):
+        x = _f32c(x, "x")
+        B, c, d, h, w = x.shape
+        y = torch.empty_like(x)
+        self._check(self.lib.mica_op_instnorm_relu(self._h, _ptr(x), B, c, d, h, w, _ptr(y), _stream()), "mica_op_instnorm_relu")
+        return y
+
+    def op_depthwise3(self, x, w, b):
+        x = _f32c(x, "x")
+        B, c, d, h, ww = x.shape
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        y = torch.empty_like(x)
+        self._check(self.lib.mica_op_depthwise3(self._h, _ptr(x), B, c, d, h, ww, w.ctypes.data_as(_cabi._FP),
+                                                b.ctypes.data_as(_cabi._FP), _ptr(y), _stream()), "mica_op_depthwise3")
+        return y
+
+    def op_stem(self, m):
+        m = _f32c(m, "map")
+        B, one, d, h, w = m.shape
+        y = torch.empty((B, 128, d, h, w), dtype=torch.float32, device=self.device)
+        self._check(self.lib.mica_op_stem(self._h, _ptr(m), B, d, h, w, _ptr(y), _stream()), "mica_op_stem")
+        return y
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.mica_set_profiling(self._h, int(on)), "mica_set_profiling")
+
+    def conv_profile(self):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self.lib.mica_get_conv_profile(self._h, C.byref(ms), C.byref(n), C.byref(fl)), "mica_get_conv_profile")
+        return ms.value, n.value, fl.value

@@ -1,0 +1,75 @@
+"""Disk-free tile -> forward -> stitch pipeline on one GPU (and its sharded multi-GPU form).
+
+Replaces the npz round trips between GridCreator, CryoEMTestDataset, CryoEMPredictor.run_inference and
+reconstruct_volume (reference utils/create_grids.py:143-176, dataset/dataset.py:194-224,
+utils/predict.py:334-376,439-512) with device-resident tensors; the four output volumes are the
+ones run_prediction() returns (utils/predict.py:589-634).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _cabi
+from .engine import AF_PER_TILE, Engine
+
+KEYS = ("backbone_probability", "carbon_alpha_probability", "amino_acid_prediction", "amino_acid_probability")
+
+
+def shard_tiles(T: int, batch: int, rank: int, world: int):
+    """Tile batches owned by `rank`: batch k of the global sequence (k = 0,1,...) covers tiles
+    [k*batch, (k+1)*batch) and belongs to rank k % world.  Every rank gets the same number of
+    batches (the tail is padded by repeating real tiles; duplicates are dropped by the caller)."""
+    nb = (T + batch - 1) // batch
+    rounds = (nb + world - 1) // world
+    out = []
+    for r in range(rounds):
+        k = r * world + rank
+        first = min(k * batch, max(T - batch, 0)) if k * batch >= T or (k + 1) * batch > T else k * batch
+        out.append((k, first))
+    return out, rounds
+
+
+class VolumePredictor:
+    def __init__(self, engine: Engine, grid_size: int = 48, padding: int = 8, batch: int | None = None):
+        if grid_size + 2 * padding != engine.tile_size:
+            raise _cabi.MicaHipError(f"grid_size + 2*padding must equal the engine's tile size {engine.tile_size}")
+        self.e, self.grid, self.pad = engine, grid_size, padding
+        self.batch = batch or engine.max_batch
+        S = engine.tile_size
+        dev = engine.device
+        B = self.batch
+        self._map_tiles = torch.empty((B, 1, S, S, S), dtype=torch.float32, device=dev)
+        self._af_tiles = torch.empty((B, 24, S, S, S), dtype=torch.float32, device=dev)
+        # one record per tile: [bb, ca, aa_pred, aa_prob x20] = 23 channels
+        self._rec = torch.empty((B, 23, S, S, S), dtype=torch.float32, device=dev)
+
+    def run_batch(self, vol, af_vol, first: int, count: int):
+        """tiles first..first+count-1 -> record tensor view [count,23,S,S,S] (valid until the next call)."""
+        e = self.e
+        mt = e.gather_tiles(vol, self.grid, self.pad, first, count, out=self._map_tiles[:count])
+        at = None
+        if af_vol is not None:
+            at = e.gather_tiles(af_vol, self.grid, self.pad, first, count, out=self._af_tiles[:count])
+        rec = self._rec[:count]
+        # forward writes straight into the record's channel slices: not contiguous per tensor, so use staging views
+        S = e.tile_size
+        bbp, cap, aap, pred = e.forward_tiles(mt.view(count, S, S, S), at, af_mode=AF_PER_TILE)
+        rec[:, 0] = bbp
+        rec[:, 1] = cap
+        rec[:, 2] = pred
+        rec[:, 3:] = aap
+        return rec
+
+    def predict_volume(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None):
+        """vol f32[N0,N1,N2] on the GPU (already normalised, (x,y,z) order), af_vol f32[24,N0,N1,N2] or None.
+        Returns the dict of four device volumes with the shapes/dtypes of utils/predict.py:459-462."""
+        e = self.e
+        n0, n1, n2 = vol.shape
+        T = int(e.lib.mica_tile_count(n0, n1, n2, self.grid))
+        out = torch.zeros((23, n0, n1, n2), dtype=torch.float32, device=e.device)
+        for first in range(0, T, self.batch):
+            count = min(self.batch, T - first)
+            rec = self.run_batch(vol, af_vol, first, count)
+            e.stitch_tiles(rec, out, self.grid, self.pad, first)
+        return {"backbone_probability": out[0], "carbon_alpha_probability": out[1],
+                "amino_acid_prediction": out[2], "amino_acid_probability": out[3:]}

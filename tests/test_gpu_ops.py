@@ -1,0 +1,114 @@
+"""Per-kernel parity through the C ABI against the CPU oracle's arithmetic (torch CPU fp32 = the
+reference's L1 runtime).  Tolerance: 1e-4 relative to max(|ref|, rms(ref)) per element (BASELINE.json:
+'within 1e-4 relative fp32 per voxel'); measured errors are ~1e-6."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def rel_err(got, ref):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    scale = torch.maximum(ref.abs(), ref.pow(2).mean().sqrt().expand_as(ref))
+    return float(((got - ref).abs() / scale).max())
+
+
+@pytest.fixture(scope="module")
+def eng(weights):
+    from mica_amd.engine import Engine
+    e = Engine(0, max_batch=2, tile_size=16)
+    e.load_state_dict(weights)
+    yield e
+    e.close()
+
+
+def _rand(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+@pytest.mark.parametrize("cin,cout,k,dims", [
+    (16, 32, 3, (8, 8, 8)), (24, 64, 3, (8, 8, 16)), (64, 128, 3, (6, 10, 20)), (196, 64, 3, (8, 8, 8)),
+    (96, 32, 3, (16, 16, 16)), (128, 64, 1, (8, 8, 8)), (192, 64, 1, (4, 12, 9)), (512, 256, 1, (8, 8, 8)),
+    (32, 256, 3, (8, 8, 8)),
+])
+def test_conv3d(eng, cin, cout, k, dims):
+    x = _rand((2, cin, *dims), 1)
+    w = _rand((cout, cin, k, k, k), 2) * (3.0 / (cin * k ** 3)) ** 0.5
+    b = _rand((cout,), 3) * 0.1
+    ref = F.conv3d(x, w, b, padding=k // 2)
+    got = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), k)
+    assert rel_err(got, ref) < RTOL
+
+
+def test_conv3d_asymmetric_identity(eng):
+    """A = delta input, asymmetric weights: catches transposed MFMA operand / C-D maps."""
+    x = torch.zeros((1, 16, 8, 8, 16))
+    x[0, 3, 2, 5, 7] = 1.0
+    x[0, 11, 6, 1, 12] = -2.0
+    w = torch.arange(32 * 16 * 27, dtype=torch.float32).reshape(32, 16, 3, 3, 3) / 1000.0
+    b = torch.arange(32, dtype=torch.float32)
+    ref = F.conv3d(x, w, b, padding=1)
+    got = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3)
+    assert rel_err(got, ref) < 1e-5
+
+
+def test_conv3d_precision_split_f16(eng):
+    """The split-f16 (hi+lo) MFMA path must be ~fp32 accurate, not f16 accurate."""
+    x = _rand((1, 256, 8, 8, 8), 5, 0.0, 4.0)
+    w = _rand((64, 256, 3, 3, 3), 6) * 0.02
+    b = torch.zeros(64)
+    ref64 = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    got = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3).cpu().double()
+    ref32 = F.conv3d(x, w, b, padding=1).double()
+    e_got = float((got - ref64).abs().max() / ref64.abs().max())
+    e_f32 = float((ref32 - ref64).abs().max() / ref64.abs().max())
+    assert e_got < 2e-6, (e_got, e_f32)
+
+
+@pytest.mark.parametrize("c,dims", [(32, (8, 8, 8)), (64, (16, 16, 16)), (512, (4, 8, 8)), (8, (5, 7, 9))])
+def test_instnorm_relu(eng, c, dims):
+    x = _rand((2, c, *dims), 7) * 3.0 + 5.0     # large mean/std ratio stresses the variance
+    ref = F.relu(F.instance_norm(x, eps=1e-5))
+    got = eng.op_instnorm_relu(x.cuda())
+    assert float((got.cpu() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("c,dims", [(64, (8, 8, 8)), (128, (6, 9, 11)), (256, (8, 8, 8))])
+def test_depthwise(eng, c, dims):
+    x = _rand((2, c, *dims), 8)
+    w = _rand((c, 1, 3, 3, 3), 9) * 0.3
+    b = _rand((c,), 10) * 0.1
+    ref = F.conv3d(x, w, b, padding=1, groups=c)
+    got = eng.op_depthwise3(x.cuda(), w.numpy(), b.numpy())
+    assert rel_err(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 16, 16), (5, 9, 33)])
+def test_stem(eng, weights, dims):
+    x = _rand((2, 1, *dims), 11, 0.0, 1.0)
+    outs = []
+    for i, k in enumerate((3, 5, 7, 9)):
+        outs.append(F.conv3d(x, torch.from_numpy(weights[f"input_processing.exp_convs.{i}.weight"]),
+                             torch.from_numpy(weights[f"input_processing.exp_convs.{i}.bias"]), padding=k // 2))
+    ref = torch.cat(outs, 1)
+    got = eng.op_stem(x.cuda())
+    assert rel_err(got, ref) < 1e-5
+
+
+def test_postprocess(eng):
+    from oracle import model_oracle as mo
+    bb = _rand((2, 4, 16, 16, 16), 12) * 5
+    ca = _rand((2, 4, 16, 16, 16), 13) * 5
+    aa = _rand((2, 21, 16, 16, 16), 14) * 5
+    rb, rc, ra, rp = mo.postprocess(bb, ca, aa)
+    gb, gc, ga, gp = eng.postprocess(bb.cuda(), ca.cuda(), aa.cuda())
+    assert float((gb.cpu() - rb).abs().max()) < 1e-6
+    assert float((gc.cpu() - rc).abs().max()) < 1e-6
+    assert float((ga.cpu() - ra).abs().max()) < 1e-6
+    assert torch.equal(gp.cpu().long(), rp)
