@@ -78,12 +78,16 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
     }
 }
 
-__global__ void stats_finalize_kernel(const float* __restrict__ ws, int nblk, int C, float eps,
-                                      float* __restrict__ mean, float* __restrict__ rstd) {
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double n = 0, m = 0, q = 0;
-        for (int k = 0; k < nblk; ++k) {
+// one workgroup per (tile, 4 channels): 64 lanes merge the block partials of a channel (f64 Chan merges,
+// fixed lane->partial assignment and fixed tree => deterministic)
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ ws, int nblk, int C, float eps,
+                                                             float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double sn[256], sm[256], sq[256];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int c = blockIdx.x * 4 + (tid >> 6);
+    double n = 0, m = 0, q = 0;
+    if (c < C)
+        for (int k = lane; k < nblk; k += 64) {
             const float* w = ws + (((int64_t)b * nblk + k) * C + c) * 3;
             double nb = w[0], mb = w[1], qb = w[2];
             if (nb > 0) {
@@ -93,8 +97,28 @@ __global__ void stats_finalize_kernel(const float* __restrict__ ws, int nblk, in
                 n = nn;
             }
         }
-        mean[(int64_t)b * C + c] = (float)m;
-        rstd[(int64_t)b * C + c] = (float)(1.0 / sqrt(q / n + (double)eps));
+    sn[tid] = n; sm[tid] = m; sq[tid] = q;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+        if (lane < off) {
+            double nb = sn[tid + off], mb = sm[tid + off], qb = sq[tid + off];
+            double na = sn[tid], ma = sm[tid], qa = sq[tid];
+            if (nb > 0) {
+                if (na == 0) { na = nb; ma = mb; qa = qb; }
+                else {
+                    double nn = na + nb, dl = mb - ma;
+                    ma += dl * (nb / nn);
+                    qa += qb + dl * dl * (na * nb / nn);
+                    na = nn;
+                }
+            }
+            sn[tid] = na; sm[tid] = ma; sq[tid] = qa;
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && c < C) {
+        mean[(int64_t)b * C + c] = (float)sm[tid];
+        rstd[(int64_t)b * C + c] = (float)(1.0 / sqrt(sq[tid] / sn[tid] + (double)eps));
     }
 }
 
@@ -104,19 +128,27 @@ void launch_stats(const float* x, int B, int V, int C, float eps, float* mean, f
     int G = C / 8, SUB = 256 / G;
     int nblk = pick_blocks(V, SUB * 8, RED_BLOCKS);
     hipLaunchKernelGGL(stats_kernel, dim3(nblk, B), dim3(256), 3 * 256 * 8 * sizeof(float), st, x, V, C, ws);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd);
 }
 
-__global__ void finalize_sum_kernel(const float* __restrict__ ws, int nblocks, int C, float inv, float* __restrict__ out) {
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0.0;
-        for (int k = 0; k < nblocks; ++k) s += (double)ws[((int64_t)b * nblocks + k) * C + c];
-        out[(int64_t)b * C + c] = (float)(s * inv);
+__global__ __launch_bounds__(256) void finalize_sum_kernel(const float* __restrict__ ws, int nblocks, int C, float inv,
+                                                           float* __restrict__ out) {
+    __shared__ double sh[256];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int c = blockIdx.x * 4 + (tid >> 6);
+    double s = 0.0;
+    if (c < C)
+        for (int k = lane; k < nblocks; k += 64) s += (double)ws[((int64_t)b * nblocks + k) * C + c];
+    sh[tid] = s;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+        if (lane < off) sh[tid] += sh[tid + off];
+        __syncthreads();
     }
+    if (lane == 0 && c < C) out[(int64_t)b * C + c] = (float)(sh[tid] * inv);
 }
 void launch_finalize_sum(const float* ws, int B, int nblocks, int C, float inv, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(finalize_sum_kernel, dim3(B), dim3(256), 0, st, ws, nblocks, C, inv, out);
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, nblocks, C, inv, out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,53 @@
+"""Tile sharding across the GPUs of one node: tiles are independent, so batches
+of consecutive tiles are dealt round-robin to the ranks, each rank runs gather+forward on its own GPU,
+and one fixed-size all-gather per round (RCCL over xGMI on the GPU box, gloo in the CPU tests) brings
+the cropped per-tile records to every rank; the stitching rank scatters them into the volumes.
+
+Device-agnostic on purpose: `run_batch` and `stitch` are callables, so the rendezvous logic is
+exercised by world_size-2 gloo tests on CPU with a stand-in producer.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def batch_plan(T: int, batch: int):
+    """[(first, count)] covering tiles 0..T-1 in the reference's order."""
+    return [(f, min(batch, T - f)) for f in range(0, T, batch)]
+
+
+def rank_batches(T: int, batch: int, rank: int, world: int):
+    """Batches of `rank` as (round, first, count); every rank has the same number of rounds."""
+    plan = batch_plan(T, batch)
+    rounds = (len(plan) + world - 1) // world
+    mine = []
+    for r in range(rounds):
+        k = r * world + rank
+        mine.append((r, *plan[k]) if k < len(plan) else (r, 0, 0))
+    return mine, rounds
+
+
+def sharded_records(run_batch, stitch, T: int, batch: int, rec_shape, device, dtype=torch.float32, group=None,
+                    stitch_rank: int | None = 0):
+    """run_batch(first, count) -> tensor [count, *rec_shape] on `device`;
+    stitch(records [count, *rec_shape], first) is called on `stitch_rank` (None = every rank) for every
+    batch of every rank, in global tile order within a round."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine, rounds = rank_batches(T, batch, rank, world)
+    plan = batch_plan(T, batch)
+    send = torch.zeros((batch, *rec_shape), dtype=dtype, device=device)
+    recv = [torch.empty_like(send) for _ in range(world)] if world > 1 else None
+    for r, first, count in mine:
+        if count:
+            send[:count] = run_batch(first, count)
+        if world > 1:
+            dist.all_gather(recv, send, group=group)
+        if stitch_rank is None or rank == stitch_rank:
+            for rr in range(world):
+                k = r * world + rr
+                if k < len(plan):
+                    f, c = plan[k]
+                    stitch((recv[rr] if world > 1 else send)[:c], f)
+    return rounds

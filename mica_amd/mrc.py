@@ -1,0 +1,117 @@
+"""Minimal MRC2014 reader/writer (the `mrcfile` package is not available offline).
+
+Covers what the hot path touches (reference utils/create_grids.py:108-117,
+utils/preprocessing.py:98-107,138-148): data, voxel_size, origin, mapc/mapr/maps, n[xyz]start.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_MODES = {0: np.int8, 1: np.int16, 2: np.float32, 6: np.uint16, 12: np.float16}
+_MODE_OF = {np.dtype(v): k for k, v in _MODES.items()}
+
+
+@dataclass
+class MrcHeader:
+    nx: int = 0
+    ny: int = 0
+    nz: int = 0
+    mode: int = 2
+    nxstart: int = 0
+    nystart: int = 0
+    nzstart: int = 0
+    mx: int = 0
+    my: int = 0
+    mz: int = 0
+    cella: tuple = (0.0, 0.0, 0.0)
+    cellb: tuple = (90.0, 90.0, 90.0)
+    mapc: int = 1
+    mapr: int = 2
+    maps: int = 3
+    dmin: float = 0.0
+    dmax: float = 0.0
+    dmean: float = 0.0
+    ispg: int = 1
+    nsymbt: int = 0
+    origin: tuple = (0.0, 0.0, 0.0)
+    rms: float = 0.0
+    extra: bytes = field(default=b"", repr=False)
+
+    @property
+    def voxel_size(self):
+        """(x, y, z) Angstrom per voxel = cella / m[xyz] (mrcfile semantics)."""
+        return tuple(float(c) / m if m else 0.0 for c, m in zip(self.cella, (self.mx, self.my, self.mz)))
+
+
+def read_mrc(path: str):
+    """-> (data ndarray [nz,ny,nx] in file dtype, MrcHeader)."""
+    with open(path, "rb") as f:
+        h = f.read(1024)
+        if len(h) < 1024:
+            raise ValueError(f"{path}: truncated MRC header")
+        stamp = h[212]
+        end = ">" if stamp == 0x11 else "<"
+        ints = struct.unpack(end + "10i", h[0:40])
+        cella = struct.unpack(end + "3f", h[40:52])
+        cellb = struct.unpack(end + "3f", h[52:64])
+        mapc, mapr, maps = struct.unpack(end + "3i", h[64:76])
+        dmin, dmax, dmean = struct.unpack(end + "3f", h[76:88])
+        ispg, nsymbt = struct.unpack(end + "2i", h[88:96])
+        origin = struct.unpack(end + "3f", h[196:208])
+        rms = struct.unpack(end + "f", h[216:220])[0]
+        hd = MrcHeader(ints[0], ints[1], ints[2], ints[3], ints[4], ints[5], ints[6], ints[7], ints[8], ints[9],
+                       cella, cellb, mapc, mapr, maps, dmin, dmax, dmean, ispg, nsymbt, origin, rms)
+        if hd.mode not in _MODES:
+            raise ValueError(f"{path}: unsupported MRC mode {hd.mode}")
+        if min(hd.nx, hd.ny, hd.nz) < 1 or sorted((mapc, mapr, maps)) != [1, 2, 3]:
+            raise ValueError(f"{path}: bad MRC header (dims {hd.nx},{hd.ny},{hd.nz}; axes {mapc},{mapr},{maps})")
+        hd.extra = f.read(max(nsymbt, 0))
+        dt = np.dtype(_MODES[hd.mode]).newbyteorder(end)
+        n = hd.nx * hd.ny * hd.nz
+        data = np.fromfile(f, dtype=dt, count=n)
+        if data.size != n:
+            raise ValueError(f"{path}: truncated MRC data")
+    return data.reshape(hd.nz, hd.ny, hd.nx).astype(dt.newbyteorder("="), copy=False), hd
+
+
+def write_mrc(path: str, data: np.ndarray, voxel_size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), mapc=1, mapr=2, maps=3,
+              nxstart=0, nystart=0, nzstart=0):
+    """Little-endian MRC2014 with header statistics filled in (what mrcfile.new + set_data +
+    update_header_stats produce for the fields the path reads)."""
+    data = np.ascontiguousarray(data)
+    if data.dtype not in _MODE_OF:
+        raise ValueError(f"unsupported dtype {data.dtype}")
+    nz, ny, nx = data.shape
+    h = bytearray(1024)
+    struct.pack_into("<10i", h, 0, nx, ny, nz, _MODE_OF[data.dtype], int(nxstart), int(nystart), int(nzstart), nx, ny, nz)
+    struct.pack_into("<3f", h, 40, nx * float(voxel_size[0]), ny * float(voxel_size[1]), nz * float(voxel_size[2]))
+    struct.pack_into("<3f", h, 52, 90.0, 90.0, 90.0)
+    struct.pack_into("<3i", h, 64, int(mapc), int(mapr), int(maps))
+    d64 = data.astype(np.float64)
+    struct.pack_into("<3f", h, 76, float(d64.min()), float(d64.max()), float(d64.mean()))
+    struct.pack_into("<2i", h, 88, 1, 0)
+    struct.pack_into("<3f", h, 196, float(origin[0]), float(origin[1]), float(origin[2]))
+    h[208:212] = b"MAP "
+    h[212:216] = bytes([0x44, 0x44, 0x00, 0x00])
+    struct.pack_into("<f", h, 216, float(d64.std()))
+    struct.pack_into("<i", h, 220, 0)
+    with open(path, "wb") as f:
+        f.write(bytes(h))
+        f.write(data.astype(data.dtype.newbyteorder("<"), copy=False).tobytes())
+
+
+def transpose_to_xyz(data: np.ndarray, hd: MrcHeader):
+    """Axis-order transform of GridCreator.transpose (reference utils/create_grids.py:67-87,119-122):
+    returns the array indexed (x, y, z) and the offsets [n?start] permuted the same way."""
+    axis_order = [hd.maps - 1, hd.mapr - 1, hd.mapc - 1]
+    offset = [float(hd.nzstart), float(hd.nystart), float(hd.nxstart)]
+    trans_offset, trans_order = [], []
+    for i in range(3):
+        for j in range(3):
+            if axis_order[j] == i:
+                trans_offset.append(offset[j])
+                trans_order.append(j)
+    return np.transpose(data, trans_order), trans_offset

@@ -15,20 +15,6 @@ from .engine import AF_PER_TILE, Engine
 KEYS = ("backbone_probability", "carbon_alpha_probability", "amino_acid_prediction", "amino_acid_probability")
 
 
-def shard_tiles(T: int, batch: int, rank: int, world: int):
-    """Tile batches owned by `rank`: batch k of the global sequence (k = 0,1,...) covers tiles
-    [k*batch, (k+1)*batch) and belongs to rank k % world.  Every rank gets the same number of
-    batches (the tail is padded by repeating real tiles; duplicates are dropped by the caller)."""
-    nb = (T + batch - 1) // batch
-    rounds = (nb + world - 1) // world
-    out = []
-    for r in range(rounds):
-        k = r * world + rank
-        first = min(k * batch, max(T - batch, 0)) if k * batch >= T or (k + 1) * batch > T else k * batch
-        out.append((k, first))
-    return out, rounds
-
-
 class VolumePredictor:
     def __init__(self, engine: Engine, grid_size: int = 48, padding: int = 8, batch: int | None = None):
         if grid_size + 2 * padding != engine.tile_size:
@@ -71,5 +57,29 @@ class VolumePredictor:
             count = min(self.batch, T - first)
             rec = self.run_batch(vol, af_vol, first, count)
             e.stitch_tiles(rec, out, self.grid, self.pad, first)
+        return {"backbone_probability": out[0], "carbon_alpha_probability": out[1],
+                "amino_acid_prediction": out[2], "amino_acid_probability": out[3:]}
+
+    def predict_volume_sharded(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None, group=None):
+        """Multi-GPU form: every rank holds the (normalised) volume, runs its share of the tile batches and
+        the cropped records are all-gathered (RCCL); rank 0 returns the dict, the other ranks return None."""
+        import torch.distributed as dist
+        from .dist import sharded_records
+        e = self.e
+        n0, n1, n2 = vol.shape
+        T = int(e.lib.mica_tile_count(n0, n1, n2, self.grid))
+        g, p = self.grid, self.pad
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        out = torch.zeros((23, n0, n1, n2), dtype=torch.float32, device=e.device) if rank == 0 else None
+
+        def run(first, count):
+            return self.run_batch(vol, af_vol, first, count)[:, :, p:p + g, p:p + g, p:p + g]
+
+        def stitch(rec, first):
+            e.stitch_tiles(rec.contiguous(), out, g, 0, first)      # cropped records: window = grid, no halo
+
+        sharded_records(run, stitch, T, self.batch, (23, g, g, g), e.device, group=group, stitch_rank=0)
+        if rank != 0:
+            return None
         return {"backbone_probability": out[0], "carbon_alpha_probability": out[1],
                 "amino_acid_prediction": out[2], "amino_acid_probability": out[3:]}

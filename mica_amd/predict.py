@@ -1,0 +1,149 @@
+"""CryoEMPredictor with the reference's outer boundary (reference utils/predict.py:40-634): same
+constructor, `run_prediction() -> (success, volumes)` with the four arrays Solver.nnPred consumes
+(utils/modeler.py:735-738), same "(False, {}) + log" failure convention - but tiles go
+file -> GPU -> network -> softmax/argmax -> stitch without the per-tile .npz spill, and nothing runs
+on the CPU except file reading."""
+from __future__ import annotations
+
+import glob
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from .dataset import CryoEMTestDataset
+from .engine import AF_PER_TILE, Engine
+from .weights import load_checkpoint_state_dict
+
+KEYS = ("backbone_probability", "carbon_alpha_probability", "amino_acid_prediction", "amino_acid_probability")
+
+
+class CryoEMPredictor:
+    def __init__(self, model_path, grids_path, output_path, save_output=True, device="cuda", quiet=False, batch_size=8):
+        self.model_path = model_path
+        self.grids_path = grids_path
+        self.output_path = output_path
+        self.reconstruction_path = os.path.join(output_path, "results", os.path.normpath(self.grids_path).split(os.sep)[-1])
+        self.save_output = save_output.lower() == 'true' if isinstance(save_output, str) else bool(save_output)
+        self.device = device
+        self.quiet = quiet
+        self.batch_size = batch_size
+        self.engine = None
+        self.sample_count = 0
+        self.timing_stats = {k: 0 for k in ('strategy_selection', 'model_loading', 'data_loading', 'inference',
+                                            'reconstruction', 'saving', 'total')}
+        self.logger = logging.getLogger(__name__)
+
+    def _print_status(self, m):
+        if not self.quiet:
+            print(m)
+
+    # ---- steps (names as in the reference) ----------------------------------------------------------
+    def select_processing_strategy(self):
+        t0 = time.time()
+        files = glob.glob(f"{self.grids_path}/normalized_map_grids/*.npz")
+        self.sample_count = len(files)
+        self.timing_stats['strategy_selection'] = time.time() - t0
+        if not files:
+            self.logger.error(f"No grid files found in: {self.grids_path}/normalized_map_grids/")
+            return False
+        return True
+
+    def load_model(self, tile_size=64):
+        t0 = time.time()
+        try:
+            if not os.path.exists(self.model_path):
+                self.logger.error(f"Model file not found: {self.model_path}")
+                return False
+            if str(self.device).startswith("cpu"):
+                raise RuntimeError("device='cpu': this build runs on MI355X only (no CPU path)")
+            sd = load_checkpoint_state_dict(self.model_path)
+            dev = torch.device(self.device if ":" in str(self.device) else "cuda:0")
+            self.engine = Engine(dev, max_batch=self.batch_size, tile_size=tile_size)
+            self.engine.load_state_dict(sd)
+            self.timing_stats['model_loading'] = time.time() - t0
+            return True
+        except Exception as e:
+            self.logger.error(f"Model loading failed: {e}")
+            self.timing_stats['model_loading'] = time.time() - t0
+            return False
+
+    def prepare_data(self):
+        files = glob.glob(f"{self.grids_path}/normalized_map_grids/*.npz")
+        if not files:
+            self.logger.error(f"No grid files found in: {self.grids_path}/normalized_map_grids/")
+            return False, None
+        return True, CryoEMTestDataset(data_dir=files, transform=None)
+
+    def run_inference(self, dataset):
+        """Forward over all tiles and stitch (predict.py:307-398 + 439-512 fused).  Returns the volume dict or None."""
+        t0 = time.time()
+        try:
+            e = self.engine
+            S = e.tile_size
+            meta = []
+            for idx in range(len(dataset)):
+                d = np.load(dataset.data_dir[idx])
+                meta.append((int(d['i']), int(d['j']), int(d['k']), tuple(int(x) for x in np.asarray(d['orig_shape']).flatten()),
+                             int(d['grid_size']) if 'grid_size' in d else 48, int(d['padding']) if 'padding' in d else 8))
+            shape, grid, pad = meta[0][3], meta[0][4], meta[0][5]
+            if grid + 2 * pad != S:
+                raise RuntimeError(f"tile window {grid + 2 * pad} does not match the engine's {S}")
+            nt1, nt2 = -(-shape[1] // grid), -(-shape[2] // grid)
+            order = sorted(range(len(meta)), key=lambda t: ((meta[t][0] // grid) * nt1 + meta[t][1] // grid) * nt2 + meta[t][2] // grid)
+            tindex = lambda t: ((meta[t][0] // grid) * nt1 + meta[t][1] // grid) * nt2 + meta[t][2] // grid
+            out = torch.zeros((23, *shape), dtype=torch.float32, device=e.device)
+            B = self.batch_size
+            rec = torch.empty((B, 23, S, S, S), dtype=torch.float32, device=e.device)
+            pos = 0
+            while pos < len(order):
+                run = [order[pos]]
+                while len(run) < B and pos + len(run) < len(order) and tindex(order[pos + len(run)]) == tindex(run[-1]) + 1:
+                    run.append(order[pos + len(run)])
+                items = [dataset[t] for t in run]
+                x = torch.from_numpy(np.stack([it[0] for it in items])).to(e.device)
+                afh = np.stack([it[1] for it in items])
+                af = torch.from_numpy(afh).to(e.device) if np.any(afh) else None
+                n = len(run)
+                bbp, cap, aap, pred = e.forward_tiles(x.view(n, S, S, S), af, af_mode=AF_PER_TILE)
+                rec[:n, 0], rec[:n, 1], rec[:n, 2] = bbp, cap, pred
+                rec[:n, 3:] = aap
+                e.stitch_tiles(rec[:n], out, grid, pad, tindex(run[0]))
+                pos += n
+            vols = {"backbone_probability": out[0].cpu().numpy(), "carbon_alpha_probability": out[1].cpu().numpy(),
+                    "amino_acid_prediction": out[2].cpu().numpy(), "amino_acid_probability": out[3:].cpu().numpy()}
+            self.timing_stats['inference'] = time.time() - t0
+            return vols
+        except Exception as e:
+            self.logger.error(f"Inference failed: {e}")
+            self.timing_stats['inference'] = time.time() - t0
+            return None
+
+    def run_prediction(self):
+        t0 = time.time()
+        try:
+            if not self.select_processing_strategy():
+                return False, {}
+            if not self.load_model():
+                return False, {}
+            ok, dataset = self.prepare_data()
+            if not ok:
+                return False, {}
+            vols = self.run_inference(dataset)
+            if vols is None:
+                return False, {}
+            if self.save_output:
+                os.makedirs(self.reconstruction_path, exist_ok=True)
+                for k, v in vols.items():
+                    np.save(f'{self.reconstruction_path}/{k}.npy', v)
+            self.timing_stats['total'] = time.time() - t0
+            return True, vols
+        except Exception as e:
+            self.logger.error(f"Prediction pipeline failed: {e}")
+            return False, {}
+        finally:
+            if self.engine is not None:
+                self.engine.close()
+                self.engine = None

@@ -1,0 +1,68 @@
+"""DataPreprocessor.resample_and_normalize_map with the reference's interface and side effect
+(reference utils/preprocessing.py:30-170): reads the MRC, resamples to 1 Angstrom, normalises on the
+GPU (exact median / 99.9th-percentile select, libmica_hip.so) and writes
+<dirname(AF3_results)>/resampled_normalized_map.mrc.
+
+Scope note: the cubic-spline resample for voxel sizes other than 1 A is still scipy on the host (SURVEY.md
+8f rank 2); `create_AF3_encodings` (PDB -> 24 rasters, needs Bio.PDB) is outside this build."""
+from __future__ import annotations
+
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import mrc
+from .engine import Engine, MicaHipError
+
+
+class DataPreprocessor:
+    def __init__(self, map_path, AF3_results, quiet=False, engine: Engine | None = None, device=0):
+        self.map_path = map_path
+        self.AF3_results = AF3_results
+        self.quiet = quiet
+        self.normalized_map_path = None
+        self.logger = logging.getLogger(__name__)
+        self._engine = engine
+        self._device = device
+
+    def print_clean(self, message):
+        if not self.quiet:
+            print(message)
+
+    def normalize_array(self, data: np.ndarray, voxel_size=(1.0, 1.0, 1.0), target_voxel_size=1.0):
+        """preprocessing.py:111-133 on an array: returns (float32 map in [0,1], median, percentile).
+        Raises MicaHipError where the reference logs 'Normalization failed'."""
+        zf = [voxel_size[0] / target_voxel_size, voxel_size[1] / target_voxel_size, voxel_size[2] / target_voxel_size]
+        if all(f == 1.0 for f in zf) and np.isfinite(data).all():
+            res = data          # zoom(order=3) with unit factors reproduces finite float32 input exactly
+        else:
+            from scipy.ndimage import zoom
+            res = zoom(data, zf, order=3)                                   # :117
+        eng = self._engine or Engine(self._device, max_batch=1, tile_size=64)
+        self._engine = eng
+        if res.dtype != np.float32:
+            raise MicaHipError(f"map dtype {res.dtype}: the GPU normaliser takes float32 (MRC mode 2) maps")
+        t = torch.from_numpy(np.ascontiguousarray(res)).to(eng.device)
+        med, pct = eng.normalise_map_(t)
+        return t.cpu().numpy(), med, pct
+
+    def resample_and_normalize_map(self, target_voxel_size=1.0):
+        """Side effect and messages as preprocessing.py:80-170; returns None."""
+        success = False
+        try:
+            data, hd = mrc.read_mrc(self.map_path)
+            out, _, _ = self.normalize_array(np.asarray(data), hd.voxel_size, target_voxel_size)
+            self.normalized_map_path = os.path.join(os.path.dirname(self.AF3_results), 'resampled_normalized_map.mrc')
+            mrc.write_mrc(self.normalized_map_path, out.astype(np.float32),
+                          voxel_size=(target_voxel_size,) * 3, origin=hd.origin, mapc=hd.mapc, mapr=hd.mapr, maps=hd.maps,
+                          nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart)
+            success = True
+        except Exception as e:
+            self.logger.error(f"Map processing failed: {e}")
+        self.print_clean("Map successfully resampled and normalized." if success else "Map Resampling and Normalization Failed")
+
+    def create_AF3_encodings(self, *a, **k):
+        raise NotImplementedError("AF3 encoding rasterisation (Bio.PDB based, preprocessing.py:225-347) is outside this build; "
+                                  "provide the 24 *_encoding.mrc files")

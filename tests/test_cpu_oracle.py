@@ -1,0 +1,184 @@
+"""CPU suite: the oracle against the committed golden vectors (which the reference's own code produced,
+oracle/gen_golden.py), host-side logic, and the C ABI's symbol table.  No GPU needed."""
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from mica_amd.synth import synth_af, synth_density
+from oracle import model_oracle as mo
+from oracle import volume_oracle as vo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("S,tag", [(8, "af"), (8, "zeroaf"), (16, "af")])
+def test_model_oracle_matches_reference_golden(weights, golden_dir, S, tag):
+    g = np.load(os.path.join(golden_dir, f"model_S{S}_{tag}.npz"))
+    seed, afp = int(g["seed"]), float(g["afp"])
+    x = torch.from_numpy(synth_density((1, 1, S, S, S), seed))
+    af = torch.from_numpy(synth_af((S, S, S), seed, afp))[None]
+    if tag == "zeroaf":
+        af = torch.zeros_like(af)
+    torch.set_num_threads(8)
+    bb, ca, aa, inter = mo.mica_forward(weights, x, af, return_intermediates=True)
+    # same machine class + same ATen kernels => tight; the thread count changes summation order (~3e-5 scaled)
+    for got, key in ((bb, "bb"), (ca, "ca"), (aa, "aa")):
+        ref = g[key]
+        scale = np.maximum(np.abs(ref), np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+        assert np.max(np.abs(got.numpy() - ref) / scale) < 1e-4
+    if S == 8 and tag == "af":
+        for k in ("stem", "enc0", "enc1", "enc2", "fpn"):
+            ref = g["inter_" + k]
+            assert np.max(np.abs(inter[k].numpy() - ref)) < 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_batchwide_gating_quirk(weights, golden_dir):
+    """model.py:60: a zero-AF tile batched with a non-zero one takes the AF branch (SURVEY hard part 4)."""
+    g = np.load(os.path.join(golden_dir, "model_S8_batchwide.npz"))
+    S = 8
+    x = torch.from_numpy(synth_density((2, 1, S, S, S), 21))
+    af = torch.stack([torch.zeros(24, S, S, S), torch.from_numpy(synth_af((S, S, S), 21, 0.02))])
+    bb, ca, aa = mo.mica_forward(weights, x, af)
+    assert np.abs(bb.numpy() - g["bb"]).max() < 1e-3
+    pb, _, _ = mo.mica_forward_per_tile(weights, x, af)
+    assert float((pb[0] - bb[0]).abs().max()) > 1e-3          # per-tile gating differs on the zero-AF tile
+    assert float((pb[1] - bb[1]).abs().max()) < 1e-3
+
+
+def test_postprocess_properties():
+    g = torch.Generator().manual_seed(3)
+    bb, ca, aa = (torch.randn((2, c, 4, 4, 4), generator=g) * 3 for c in (4, 4, 21))
+    pb, pc, pa, pp = mo.postprocess(bb, ca, aa)
+    assert pb.shape == (2, 4, 4, 4) and pa.shape == (2, 20, 4, 4, 4) and pp.dtype == torch.int64
+    assert torch.allclose(pa.sum(1), torch.ones(2, 4, 4, 4), atol=1e-6)
+    assert torch.equal(pp, aa[:, 1:].argmax(1))
+    # class 1 is dropped: changing it must not change the probability (predict.py:342)
+    bb2 = bb.clone(); bb2[:, 1] += 100
+    assert torch.equal(mo.postprocess(bb2, ca, aa)[0], pb)
+
+
+def test_tiler_oracle_vs_golden_and_survey_facts(golden_dir):
+    tiler = json.load(open(os.path.join(golden_dir, "tiler.json")))
+    for key, rec in tiler.items():
+        shape = tuple(int(v) for v in key.split("x"))
+        tiles, idx = vo.tile_volume(synth_density(shape, rec["seed"]), 48, 8)
+        assert idx.tolist() == rec["idx"]
+        assert sha(tiles) == rec["tiles_sha256"]
+        assert len(idx) == np.prod([-(-s // 48) for s in shape])
+    # facts the survey recorded from the reference's own GridCreator
+    tv, off = vo.transpose_axes(np.zeros((100, 70, 50), np.float32), 1, 2, 3, [7, 6, 5])
+    assert tv.shape == (50, 70, 100) and off == [5.0, 6.0, 7.0]
+    _, idx = vo.tile_volume(tv, 48, 8)
+    assert len(idx) == 12 and idx[-1].tolist() == [48, 48, 96, 2, 22, 4]
+    tv2, off2 = vo.transpose_axes(np.zeros((100, 70, 50), np.float32), 3, 2, 1, [7, 6, 5])
+    assert tv2.shape == (100, 70, 50) and off2 == [7.0, 6.0, 5.0]
+
+
+@pytest.mark.parametrize("shape,grid,pad", [((50, 70, 100), 48, 8), ((96, 96, 96), 48, 8), ((33, 64, 7), 32, 16), ((5, 5, 5), 48, 8)])
+def test_tile_stitch_round_trip_and_c_table(shape, grid, pad):
+    """tile -> stitch is the identity; the C ABI's host-side tile table equals the oracle's bit for bit."""
+    from mica_amd._cabi import tile_table
+    vol = synth_density(shape, 9)
+    tiles, idx = vo.tile_volume(vol, grid, pad)
+    assert np.array_equal(vo.stitch_volume(tiles, idx, shape, pad), vol)
+    multi = np.stack([tiles, tiles * 2], axis=1)
+    assert np.array_equal(vo.stitch_volume(multi, idx, shape, pad)[1], vol * 2)
+    assert np.array_equal(tile_table(*shape, grid), idx)
+    # N % grid == 0 edge case: the last window still exists and pad_end = window (create_grids.py:130)
+    if shape == (96, 96, 96):
+        assert len(idx) == 8 and tiles.shape[1:] == (64, 64, 64)
+
+
+def test_normaliser_oracle_vs_golden(golden_dir):
+    norm = json.load(open(os.path.join(golden_dir, "normaliser.json")))
+    for n in ("40", "64"):
+        rec = norm[n]
+        vol = (synth_density((int(n),) * 3, rec["seed"]) - 0.3) * 3.0
+        out, med, pct = vo.normalise_map(vol)
+        assert med == rec["median"] and pct == rec["percentile"] and sha(out) == rec["sha256"]
+        assert out.dtype == np.float32 and out.min() == 0.0 and out.max() == 1.0
+    rec = norm["zoom_20x24x28"]
+    out, med, pct = vo.normalise_map(synth_density((20, 24, 28), rec["seed"]) - 0.3, voxel_size=tuple(rec["voxel"]))
+    assert list(out.shape) == rec["shape"] and sha(out) == rec["sha256"]
+    vol = synth_density((16, 16, 16), norm["nan_16"]["seed"]) - 0.3
+    vol[1, 2, 3] = np.nan
+    with pytest.raises(ValueError, match="No positive values"):
+        vo.normalise_map(vol)
+
+
+def test_weights_table_and_generator_are_stable(weights):
+    from mica_amd.weights import param_shapes, synth_state_dict
+    shapes = param_shapes()
+    assert len(shapes) == 125 and sum(int(np.prod(s)) for s in shapes.values()) == 14127813
+    again = synth_state_dict(2022)
+    h = hashlib.sha256()
+    for k in shapes:
+        assert weights[k].dtype == np.float32 and weights[k].shape == shapes[k]
+        assert np.array_equal(weights[k], again[k])
+        h.update(weights[k].tobytes())
+    # pins the generator across hosts / numpy versions: golden vectors depend on it
+    assert h.hexdigest()[:16] == WEIGHTS_SHA16
+
+
+WEIGHTS_SHA16 = "14f1324fa67c233e"
+
+
+def test_checkpoint_loader_round_trip(tmp_path, weights):
+    from mica_amd.weights import load_checkpoint_state_dict
+    p = tmp_path / "ck.pth"
+    torch.save({"epoch": 3, "model_state_dict": {"module." + k: torch.from_numpy(v.copy()) for k, v in weights.items()},
+                "val_loss": 0.1}, p)                         # reference train.py:298-304 format
+    sd = load_checkpoint_state_dict(str(p))
+    assert set(sd) == set(weights) and all(np.array_equal(sd[k], weights[k]) for k in weights)
+    bad = dict(weights); bad.pop("fpn.weights")
+    torch.save({"model_state_dict": {k: torch.from_numpy(v.copy()) for k, v in bad.items()}}, p)
+    with pytest.raises(KeyError):
+        load_checkpoint_state_dict(str(p))
+
+
+def test_cabi_exports_every_declared_symbol():
+    """include/mica_hip.h <-> ctypes table <-> the built .so (no compute calls: no GPU here)."""
+    from mica_amd import _cabi
+    hdr = open(os.path.join(ROOT, "include", "mica_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mica_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_cabi.SIGNATURES), declared ^ set(_cabi.SIGNATURES)
+    lib = _cabi.load_library()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mica_abi_version() == 1
+    assert lib.mica_tile_count(512, 512, 512, 48) == 1331 and lib.mica_tile_count(256, 256, 256, 32) == 512
+    assert lib.mica_tile_count(0, 1, 1, 48) < 0
+
+
+def test_product_fails_loudly_without_gpu():
+    from mica_amd.engine import Engine, MicaHipError
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(MicaHipError, match="no CPU fallback"):
+        Engine(0)
+    from mica_amd.model import MICA
+    with pytest.raises(MicaHipError):
+        MICA().to("cpu")
+
+
+def test_missing_library_is_an_error(tmp_path):
+    from mica_amd import _cabi
+    with pytest.raises(_cabi.MicaHipError, match="not found"):
+        _cabi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_product_never_imports_oracle():
+    for fn in os.listdir(os.path.join(ROOT, "mica_amd")):
+        if fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "mica_amd", fn)).read()
+            assert "oracle" not in src, fn

@@ -1,0 +1,205 @@
+"""Tiler / stitch / normaliser / predictor parity on the GPU (bit-exact for the copies and the select)."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mica_amd.synth import synth_af, synth_density
+from oracle import volume_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def eng(weights):
+    from mica_amd.engine import Engine
+    e = Engine(0, max_batch=2, tile_size=64)
+    e.load_state_dict(weights)
+    yield e
+    e.close()
+
+
+def test_gather_tiles_bit_exact_vs_oracle_and_golden(eng, golden_dir):
+    tiler = json.load(open(os.path.join(golden_dir, "tiler.json")))
+    for key, rec in tiler.items():
+        shape = tuple(int(v) for v in key.split("x"))
+        vol = synth_density(shape, rec["seed"])
+        ref, idx = vo.tile_volume(vol, 48, 8)
+        got = eng.gather_tiles(torch.from_numpy(vol).cuda(), 48, 8, 0, len(idx)).cpu().numpy()[:, 0]
+        assert np.array_equal(got, ref) and sha(got) == rec["tiles_sha256"]
+
+
+def test_gather_multichannel_ranges_and_other_tilings(eng):
+    from mica_amd.engine import Engine
+    vol = np.stack([synth_density((70, 33, 50), s) for s in (1, 2, 3)])
+    e32 = Engine(0, max_batch=1, tile_size=64)
+    for grid, pad in ((48, 8), (32, 16)):
+        refs = [vo.tile_volume(v, grid, pad) for v in vol]
+        T = len(refs[0][1])
+        got = e32.gather_tiles(torch.from_numpy(vol).cuda(), grid, pad, 1, T - 1).cpu().numpy()
+        for c in range(3):
+            assert np.array_equal(got[:, c], refs[c][0][1:])
+    e32.close()
+
+
+def test_stitch_bit_exact_and_round_trip_full_size(eng):
+    shape = (50, 70, 100)
+    rec = np.stack([synth_density((12, 64, 64, 64), s) for s in (4, 5)], axis=1)    # [T=12, C=2, W,W,W]
+    _, idx = vo.tile_volume(np.zeros(shape, np.float32), 48, 8)
+    out = torch.zeros((2, *shape), device="cuda")
+    eng.stitch_tiles(torch.from_numpy(rec).cuda(), out, 48, 8, 0)
+    assert np.array_equal(out.cpu().numpy(), vo.stitch_volume(rec, idx, shape, 8))
+    # size-independent property at a BASELINE-size map: gather -> stitch is the identity (256^3, 216 tiles)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    vol = torch.rand((256, 256, 256), generator=g, device="cuda")
+    back = torch.zeros_like(vol)
+    T = int(eng.lib.mica_tile_count(256, 256, 256, 48))
+    assert T == 216
+    for first in range(0, T, 27):
+        eng.stitch_tiles(eng.gather_tiles(vol, 48, 8, first, 27), back, 48, 8, first)
+    assert torch.equal(back, vol)
+
+
+def test_normalise_bit_exact_vs_golden(eng, golden_dir):
+    norm = json.load(open(os.path.join(golden_dir, "normaliser.json")))
+    for n in ("40", "64"):
+        rec = norm[n]
+        vol = (synth_density((int(n),) * 3, rec["seed"]) - 0.3) * 3.0
+        t = torch.from_numpy(vol).cuda()
+        med, pct = eng.normalise_map_(t)
+        assert med == rec["median"] and pct == rec["percentile"]
+        assert sha(t.cpu().numpy()) == rec["sha256"]
+    # odd element count, +-inf, NaN (no spline prefilter on this entry point: nan_to_num semantics only)
+    vol = (synth_density((11, 13, 9), 5) - 0.5)
+    vol[0, 0, 0], vol[1, 1, 1], vol[2, 2, 2] = np.nan, np.inf, -np.inf
+    x = np.nan_to_num(vol)
+    med = np.median(x)
+    m = (x > med) * (x - med)
+    pct = np.percentile(m[m > 0], 99.9)
+    ref = ((m < pct) * m + (m >= pct) * pct) / pct
+    t = torch.from_numpy(vol).cuda()
+    gm, gp = eng.normalise_map_(t)
+    assert gm == float(med) and gp == float(pct) and np.array_equal(t.cpu().numpy(), ref.astype(np.float32))
+    from mica_amd.engine import MicaHipError
+    with pytest.raises(MicaHipError, match="No positive values"):
+        eng.normalise_map_(torch.zeros((8, 8, 8), device="cuda"))
+
+
+def test_normalise_large_map_properties(eng):
+    """256^3: output in [0,1], zeros exactly where x <= median, idempotent ranks."""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    vol = torch.randn((256, 256, 256), generator=g, device="cuda")
+    ref_med = vol.flatten().sort().values[[256 ** 3 // 2 - 1, 256 ** 3 // 2]]
+    x = vol.clone()
+    med, pct = eng.normalise_map_(x)
+    assert med == float((ref_med[0] + ref_med[1]) / 2)
+    assert float(x.min()) == 0.0 and float(x.max()) == 1.0
+    assert torch.equal(x == 0, vol <= med)
+    assert abs(float((x == 1).float().mean()) - 0.5 * 1e-3) < 2e-5
+
+
+def _scaled(got, ref):
+    ref = ref.astype(np.float64)
+    return float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), np.sqrt(np.mean(ref ** 2)))))
+
+
+def test_predictor_end_to_end_vs_reference_golden(tmp_path, weights, golden_dir):
+    """The reference's CryoEMPredictor.run_prediction on a 60x40x40 map (2 tiles) is the golden."""
+    from mica_amd.predict import CryoEMPredictor
+    g = np.load(os.path.join(golden_dir, "predictor_60x40x40.npz"))
+    shape = tuple(int(v) for v in g["shape"])
+    vol = synth_density(shape, int(g["seed"]))
+    tiles, idx = vo.tile_volume(vol, 48, 8)
+    gdir = tmp_path / "grids" / "normalized_map_grids"
+    os.makedirs(gdir)
+    for t, (i, j, k, di, dj, dk) in enumerate(idx):
+        np.savez(gdir / f"normalized_map_grid_i{i}_j{j}_k{k}.npz", grid=tiles[t], i=i, j=j, k=k, di=di, dj=dj, dk=dk,
+                 orig_shape=shape, grid_size=48, padding=8)
+    ck = str(tmp_path / "ckpt.pth")
+    torch.save({"epoch": 0, "model_state_dict": {"module." + k: torch.from_numpy(v.copy()) for k, v in weights.items()}}, ck)
+    pred = CryoEMPredictor(model_path=ck, grids_path=str(tmp_path / "grids") + "/", output_path=str(tmp_path / "out"),
+                           save_output=True, device="cuda", quiet=True)
+    ok, vols = pred.run_prediction()
+    assert ok and set(vols) == {"backbone_probability", "carbon_alpha_probability", "amino_acid_prediction", "amino_acid_probability"}
+    for k in vols:
+        assert vols[k].dtype == np.float32
+    assert vols["amino_acid_probability"].shape == (20, *shape) and vols["backbone_probability"].shape == shape
+    assert np.abs(vols["backbone_probability"] - g["backbone_probability"]).max() < 1e-4
+    assert np.abs(vols["carbon_alpha_probability"] - g["carbon_alpha_probability"]).max() < 1e-4
+    sub = vols["amino_acid_probability"][:, ::2, ::2, ::2]
+    assert np.abs(sub - g["amino_acid_probability_sub"]).max() < 1e-4
+    top = np.sort(vols["amino_acid_probability"], axis=0)
+    gap = top[-1] - top[-2]
+    mism = vols["amino_acid_prediction"].astype(np.int64) != g["amino_acid_prediction"].astype(np.int64)
+    assert not np.any(mism & (gap > 2e-4)) and mism.mean() < 1e-3
+    assert os.path.exists(tmp_path / "out" / "results" / "grids" / "backbone_probability.npy")
+
+
+def test_in_memory_pipeline_equals_tile_files_and_gating_is_per_tile(eng, weights):
+    """VolumePredictor (no disk) on a map whose AF3 encodings touch only one of the two tiles."""
+    from mica_amd.pipeline import VolumePredictor
+    from oracle import model_oracle as mo
+    shape = (60, 40, 40)
+    vol = synth_density(shape, 41)
+    af = np.zeros((24, *shape), np.float32)
+    af[:, 56:60, 10:30, 10:30] = synth_af((4, 20, 20), 3, 0.05)       # tile 0's window ends at index 55: only tile 1 sees them
+    vp = VolumePredictor(eng, 48, 8, batch=2)
+    out = vp.predict_volume(torch.from_numpy(vol).cuda(), torch.from_numpy(af).cuda())
+    tiles, idx = vo.tile_volume(vol, 48, 8)
+    aft = np.stack([vo.tile_volume(a, 48, 8)[0] for a in af], axis=1)
+    assert not aft[0].any() and aft[1].any()
+    lb, lc, la = mo.mica_forward_per_tile(weights, torch.from_numpy(tiles[:, None]), torch.from_numpy(aft))
+    pb, pc, pa, pp = mo.postprocess(lb, lc, la)
+    ref_bb = vo.stitch_volume(pb.numpy(), idx, shape, 8)
+    ref_aa = vo.stitch_volume(pa.numpy(), idx, shape, 8)
+    assert np.abs(out["backbone_probability"].cpu().numpy() - ref_bb).max() < 1e-4
+    assert np.abs(out["amino_acid_probability"].cpu().numpy() - ref_aa).max() < 1e-4
+    assert out["amino_acid_prediction"].dtype == torch.float32
+
+
+def test_gridcreator_and_preprocessor_mirrors(tmp_path, eng):
+    from mica_amd import mrc
+    from mica_amd.create_grids import GridCreator
+    from mica_amd.preprocessing import DataPreprocessor
+    raw = ((synth_density((40, 50, 60), 7) - 0.3) * 3.0).astype(np.float32)          # [nz,ny,nx]
+    os.makedirs(tmp_path / "in" / "af3")
+    mp = str(tmp_path / "in" / "emd.mrc")
+    mrc.write_mrc(mp, raw, nxstart=5, nystart=6, nzstart=7)
+    dp = DataPreprocessor(mp, str(tmp_path / "in" / "af3"), quiet=True)
+    dp.resample_and_normalize_map()
+    assert dp.normalized_map_path == str(tmp_path / "in" / "resampled_normalized_map.mrc")
+    normed, hd = mrc.read_mrc(dp.normalized_map_path)
+    ref, _, _ = vo.normalise_map(raw)
+    assert np.array_equal(normed, ref) and (hd.nxstart, hd.nystart, hd.nzstart) == (5, 6, 7)
+    gc = GridCreator(quiet=True)
+    res = gc.create_normalized_map_grids(dp.normalized_map_path, str(tmp_path / "grids" / "normalized_map_grids"))
+    vol, off = vo.transpose_axes(ref, 1, 2, 3, [7, 6, 5])
+    tiles, idx = vo.tile_volume(vol, 48, 8)
+    assert res["success"] and res["grid_count"] == len(idx) == 4 and res["offset"] == off == [5.0, 6.0, 7.0]
+    files = glob.glob(str(tmp_path / "grids" / "normalized_map_grids" / "*.npz"))
+    assert len(files) == 4
+    for t, (i, j, k, di, dj, dk) in enumerate(idx):
+        d = np.load(str(tmp_path / "grids" / "normalized_map_grids" / f"normalized_map_grid_i{i}_j{j}_k{k}.npz"))
+        assert np.array_equal(d["grid"], tiles[t]) and (int(d["di"]), int(d["dj"]), int(d["dk"])) == (di, dj, dk)
+        assert tuple(d["orig_shape"]) == vol.shape and int(d["padding"]) == 8
+    assert gc.create_normalized_map_grids(str(tmp_path / "missing.mrc"), str(tmp_path / "x"))["success"] is False
+
+
+def test_mica_module_mirror(weights, golden_dir):
+    from mica_amd.model import MICA
+    g = np.load(os.path.join(golden_dir, "model_S8_af.npz"))
+    m = MICA().to("cuda").eval()
+    m.load_state_dict({"module." + k: v for k, v in weights.items()})
+    x = torch.from_numpy(synth_density((1, 1, 8, 8, 8), int(g["seed"])))
+    af = torch.from_numpy(synth_af((8, 8, 8), int(g["seed"]), float(g["afp"])))[None]
+    bb, ca, aa = m(x, af)
+    assert bb.shape == (1, 4, 8, 8, 8) and aa.shape == (1, 21, 8, 8, 8)
+    assert _scaled(aa.cpu().numpy(), g["aa"]) < 1e-4
