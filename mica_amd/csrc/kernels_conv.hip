@@ -5,6 +5,7 @@
 // 142,158-174,210,212.  Also: weight packing, depthwise 3^3 (model.py:80) and the Cin=1 multi-scale
 // stem (model.py:9-14).
 #include "common.h"
+#include <cstdlib>
 
 namespace mica {
 
@@ -64,27 +65,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvSrcs s, const _Fl
             for (int i = 0; i < 16; ++i) acc[f][j][i] = 0.f;
 
     const _Float16* wbase = wpk + (int64_t)b * wpk_bstride + (int64_t)nb * BN * 8;
-    // B staging: piece p = q*BN + n  ->  LDS byte p*16 ; global ((step*4 + q)*cout + n)*8 halves
-    constexpr int BP = (4 * BN + 255) / 256;
-    uint4 breg[BP];
-    auto loadB = [&](int step) {
-#pragma unroll
-        for (int i = 0; i < BP; ++i) {
-            int p = tid + 256 * i;
-            if (4 * BN >= 256 * (i + 1) || p < 4 * BN) {
-                int q = p / BN, n = p % BN;
-                breg[i] = *reinterpret_cast<const uint4*>(wbase + ((int64_t)(step * 4 + q) * cout + n) * 8);
-            }
-        }
-    };
-    auto storeB = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < BP; ++i) {
-            int p = tid + 256 * i;
-            if (4 * BN >= 256 * (i + 1) || p < 4 * BN)
-                *reinterpret_cast<uint4*>(ldsB + buf * B_BYTES + p * 16) = breg[i];
-        }
-    };
+    // B staging: piece p = q*BN + n  ->  LDS byte p*16 ; global ((step*4 + q)*cout + n)*8 halves.
+    // Two named registers (not an array behind a lambda: that ends up in scratch and serialises the prefetch).
+    constexpr bool B2 = (4 * BN > 256);          // BN=128: two pieces per thread
+    constexpr bool BPART = (4 * BN < 256);       // BN=32: only the first 128 threads stage
+    const int bp0 = tid, bp1 = tid + 256;
+    const int64_t boff0 = ((int64_t)(bp0 / BN) * cout + (bp0 % BN)) * 8;
+    const int64_t boff1 = ((int64_t)(bp1 / BN) * cout + (bp1 % BN)) * 8;
+    const int64_t bstep = (int64_t)4 * cout * 8;
+    uint4 breg0 = make_uint4(0, 0, 0, 0), breg1 = make_uint4(0, 0, 0, 0);
+#define MICA_LOADB(step)                                                                                   \
+    do {                                                                                                   \
+        if (!BPART || tid < 4 * BN) breg0 = *reinterpret_cast<const uint4*>(wbase + (step) * bstep + boff0); \
+        if (B2) breg1 = *reinterpret_cast<const uint4*>(wbase + (step) * bstep + boff1);                    \
+    } while (0)
+#define MICA_STOREB(buf)                                                                                   \
+    do {                                                                                                   \
+        if (!BPART || tid < 4 * BN) *reinterpret_cast<uint4*>(ldsB + (buf) * B_BYTES + bp0 * 16) = breg0;   \
+        if (B2) *reinterpret_cast<uint4*>(ldsB + (buf) * B_BYTES + bp1 * 16) = breg1;                       \
+    } while (0)
 
     // per-lane LDS read bases (bytes)
     const int lx = lane & 15, lzz = (lane >> 4) & 1, lh = lane >> 5;
@@ -92,28 +91,43 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvSrcs s, const _Fl
     const int b_base = (lh * BN + (lane & 31)) * 16;
 
     const int nsteps = total_chunks * G::NT;
-    loadB(0);
-    storeB(0);
+    MICA_LOADB(0);
+    MICA_STOREB(0);
 
     int gch = 0;
     for (int si = 0; si < s.n; ++si) {
         for (int ch = 0; ch < s.chunks[si]; ++ch, ++gch) {
             // ---- stage the halo'd A slab of this 16-channel chunk ------------------------------
+            // All loads are issued unconditionally from clamped (always valid) addresses and zeroed by a
+            // select afterwards: a branch around each load would make hipcc wait vmcnt(0) per piece,
+            // i.e. NP dependent HBM round trips per chunk.
             const _Float16* src =
                 s.p[si] + ((int64_t)b * s.chunks_total[si] + s.chunk_off[si] + ch) * (int64_t)V * 32;
+            constexpr int NP = (G::PIECES + 255) / 256;
+            uint4 av[NP];
 #pragma unroll
-            for (int i = 0; i < (G::PIECES + 255) / 256; ++i) {
+            for (int i = 0; i < NP; ++i) {
                 int p = tid + 256 * i;
-                if (p < G::PIECES) {
-                    int row = p / G::ROW_PIECES, within = p - row * G::ROW_PIECES;
-                    int vx = within >> 2, q = within & 3;
-                    int vy = row % G::SY, vz = row / G::SY;
-                    int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if ((unsigned)gx < (unsigned)d.W && (unsigned)gy < (unsigned)d.H && (unsigned)gz < (unsigned)d.D)
-                        v = *reinterpret_cast<const uint4*>(src + ((int64_t)(gz * d.H + gy) * d.W + gx) * 32 + q * 8);
+                p = p < G::PIECES ? p : G::PIECES - 1;
+                int row = p / G::ROW_PIECES, within = p - row * G::ROW_PIECES;
+                int vx = within >> 2, q = within & 3;
+                int vy = row % G::SY, vz = row / G::SY;
+                int gx = min(max(x0 + vx, 0), d.W - 1), gy = min(max(y0 + vy, 0), d.H - 1), gz = min(max(z0 + vz, 0), d.D - 1);
+                av[i] = *reinterpret_cast<const uint4*>(src + ((int64_t)(gz * d.H + gy) * d.W + gx) * 32 + q * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                int p = tid + 256 * i;
+                int pc = p < G::PIECES ? p : G::PIECES - 1;
+                int row = pc / G::ROW_PIECES, within = pc - row * G::ROW_PIECES;
+                int vx = within >> 2, q = within & 3;
+                int vy = row % G::SY, vz = row / G::SY;
+                int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
+                bool ok = (unsigned)gx < (unsigned)d.W && (unsigned)gy < (unsigned)d.H && (unsigned)gz < (unsigned)d.D;
+                uint4 v = av[i];
+                v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+                if (p < G::PIECES)
                     *reinterpret_cast<uint4*>(ldsA + (q * G::PLANE + vz * G::PZ + vy * G::SX + vx) * 16) = v;
-                }
             }
             __syncthreads();
             // ---- taps --------------------------------------------------------------------------
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvSrcs s, const _Fl
             for (int tap = 0; tap < G::NT; ++tap) {
                 const int g = gch * G::NT + tap;
                 const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-                if (g + 1 < nsteps) loadB(g + 1);
+                if (g + 1 < nsteps) MICA_LOADB(g + 1);
                 const char* Bb = ldsB + (g & 1) * B_BYTES;
                 half8 a[2][2];
 #pragma unroll
@@ -141,12 +155,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvSrcs s, const _Fl
                         acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bh, acc[f][j], 0, 0, 0);
                     }
                 }
-                if (g + 1 < nsteps) storeB((g + 1) & 1);
+                if (g + 1 < nsteps) MICA_STOREB((g + 1) & 1);
                 __syncthreads();
             }
         }
     }
 
+#undef MICA_LOADB
+#undef MICA_STOREB
     // ---- epilogue: out[b][voxel][n] = acc*out_scale + bias[n] ------------------------------------
     // C/D map of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
     const int col = lane & 31, rhalf = lane >> 5;
@@ -187,10 +203,258 @@ static void launch_conv_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bs
                        out, d, cout, total, ntx, nty, nnb);
 }
 
+
+// ================================================================================================
+// conv2: the same arithmetic, restructured around the measured stalls of the kernel above (57 % of the
+// wave-cycles waited at the per-tap barrier / B hand-off):
+//   * one 8-wave workgroup per CU, output tile 16(x) x 8(y) x 4(z) = 512 GEMM rows x BN channels
+//     (halo overhead 2.1x instead of 2.8x, weights fetched once per 512 rows);
+//   * the halo'd A slab is DOUBLE-buffered in LDS and filled by LDS-DMA (global_load_lds, 16 B/lane, no
+//     VGPR round trip); out-of-volume voxels are never written (exec-masked) and stay zero from a
+//     one-time clear, which implements the conv's zero padding; one barrier per 16-channel chunk;
+//   * weights are not staged in LDS: each wave loads its own B fragments straight from L1/L2 into
+//     registers one step ahead (the packed layout is contiguous in step order), so there is no per-tap
+//     barrier at all;
+//   * waves are arranged WM (rows) x WN (channels): with 4x2 a wave owns 4 row-fragments x 64 channels
+//     (24 MFMAs per tap from 8 ds_read_b128 + 4 global loads).
+// DMA issue is staggered (waves 0-3 at the first tap, waves 4-7 mid-chunk) because vmcnt retires in order:
+// a B-fragment wait behind a freshly issued DMA stalls until the DMA lands, and SIMD partners w / w+4
+// should not do that at the same time.
+// ================================================================================================
+template <int KS> struct Geo2 {
+    static constexpr int HALO = KS / 2;
+    static constexpr int SX = 16 + 2 * HALO, SY = 8 + 2 * HALO, SZ = 4 + 2 * HALO;
+    static constexpr int PZ = ((SX * SY + 63) / 64) * 64;      // slots per z plane: whole DMA instructions
+    static constexpr int PLANE = SZ * PZ;
+    static constexpr int CH_BYTES = 4 * PLANE * 16;           // one chunk image: 4 planes (hi/lo x k-half)
+    static constexpr int CPS = (KS == 3) ? 1 : 2;             // chunks per stage
+    static constexpr int STAGE_BYTES = CPS * CH_BYTES;
+    static constexpr int NT = KS * KS * KS;
+    static constexpr int DPZ = PZ / 64;                       // DMA instructions per (plane, z)
+    static constexpr int DMA_PER_CHUNK = 4 * SZ * DPZ;
+    static constexpr int DPW = DMA_PER_CHUNK / 8;             // per wave
+    static_assert(DMA_PER_CHUNK % 8 == 0, "DMA instructions must split evenly over 8 waves");
+};
+
+template <int DPW>
+__device__ __forceinline__ void issue_chunk_dma(const _Float16* __restrict__ src, char* lds_chunk, const int (&goff)[DPW],
+                                                const int (&loff)[DPW]) {
+#pragma unroll
+    for (int k = 0; k < DPW; ++k)
+        if (goff[k] >= 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + goff[k]),
+                                             (__attribute__((address_space(3))) void*)(lds_chunk + loff[k]), 16, 0, 0);
+}
+
+__device__ __forceinline__ const _Float16* chunk_base(const ConvSrcs& s, int gch, int b, int V) {
+    int si = 0, ch = gch;
+#pragma unroll
+    for (int i = 0; i < MAX_SRC - 1; ++i)
+        if (si == i && i + 1 < s.n && ch >= s.chunks[i]) { ch -= s.chunks[i]; si = i + 1; }
+    return s.p[si] + ((int64_t)b * s.chunks_total[si] + s.chunk_off[si] + ch) * (int64_t)V * 32;
+}
+
+template <int KS, int BN, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void conv2_kernel(ConvSrcs s, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
+                                                       const float* __restrict__ bias, float out_scale,
+                                                       float* __restrict__ out, Dims d, int cout, int total_chunks,
+                                                       int ntx, int nty, int nnb) {
+    using G = Geo2<KS>;
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int FM = 16 / WM;            // row fragments per wave
+    constexpr int WNC = BN / WN;           // channels per wave
+    constexpr int NJ = WNC / 32;
+    static_assert(NJ >= 1 && FM >= 1, "wave tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int b = blockIdx.y;
+    const int V = d.D * d.H * d.W;
+
+    int id = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
+    const int nb = id % nnb;
+    const int tile = id / nnb;
+    const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+    const int x0 = tx * 16 - G::HALO, y0 = ty * 8 - G::HALO, z0 = tz * 4 - G::HALO;
+
+    // one-time clear of both stage buffers (zero padding + never-written pad slots)
+    for (int i = tid; i < 2 * G::STAGE_BYTES / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+    // chunk-invariant DMA descriptors of this wave
+    int goff[G::DPW], loff[G::DPW];
+#pragma unroll
+    for (int k = 0; k < G::DPW; ++k) {
+        const int ii = wave * G::DPW + k;
+        const int q = ii / (G::SZ * G::DPZ), rem = ii % (G::SZ * G::DPZ);
+        const int vz = rem / G::DPZ, part = rem % G::DPZ;
+        const int slot = part * 64 + lane;
+        const int vy = slot / G::SX, vx = slot - vy * G::SX;
+        const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
+        const bool ok = slot < G::SX * G::SY && (unsigned)gx < (unsigned)d.W && (unsigned)gy < (unsigned)d.H &&
+                        (unsigned)gz < (unsigned)d.D;
+        goff[k] = ok ? ((gz * d.H + gy) * d.W + gx) * 32 + q * 8 : -1;
+        loff[k] = (q * G::PLANE + vz * G::PZ + part * 64) * 16;
+    }
+
+    floatx16 acc[FM][NJ];
+#pragma unroll
+    for (int f = 0; f < FM; ++f)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[f][j][i] = 0.f;
+
+    const int lx = lane & 15, lzz = (lane >> 4) & 1, lh = lane >> 5;
+    const int y_w = wm * (FM >= 2 ? FM / 2 : 1);                 // first y row of this wave (FM=4: 2 rows, FM=2: 1 row)
+    const int a_base = (lh * G::PLANE + lzz * G::PZ + y_w * G::SX + lx) * 16;
+    // B fragments come straight from L1/L2: address = wave-uniform byte base (SGPR pair, advanced per step)
+    // + a per-lane 32-bit offset that never changes => global_load saddr+voffset form, no per-tap VALU and no
+    // hoisted per-tap address registers.
+    const char* wuni = reinterpret_cast<const char*>(wpk + (int64_t)b * wpk_bstride) + (int64_t)(nb * BN + wn * WNC) * 16;
+    const unsigned wlane = (unsigned)(lh * cout + (lane & 31)) * 16u;
+    const int64_t bstep = (int64_t)4 * cout * 16;    // bytes per step
+    const int64_t bkind = (int64_t)2 * cout * 16;    // bytes hi-plane -> lo-plane
+    const int nsteps = total_chunks * G::NT;
+    const int nstages = (total_chunks + G::CPS - 1) / G::CPS;
+
+    half8 bnx[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) bnx[j][kind] = *reinterpret_cast<const half8*>(wuni + kind * bkind + j * 512 + wlane);
+
+    __syncthreads();   // clear done before any DMA lands
+#pragma unroll
+    for (int c = 0; c < G::CPS; ++c)
+        if (c < total_chunks) issue_chunk_dma<G::DPW>(chunk_base(s, c, b, V), smem + c * G::CH_BYTES, goff, loff);
+    __syncthreads();   // (the compiler drains vmcnt before the barrier)
+
+    int g = 0;
+    for (int st = 0; st < nstages; ++st) {
+        char* cur = smem + (st & 1) * G::STAGE_BYTES;
+        char* nxt = smem + ((st + 1) & 1) * G::STAGE_BYTES;
+        const bool have_next = st + 1 < nstages;
+#pragma unroll
+        for (int c = 0; c < G::CPS; ++c) {
+            const int gch = st * G::CPS + c;
+            if (gch < total_chunks) {
+                const char* A = cur + c * G::CH_BYTES + a_base;
+#pragma unroll
+                for (int tap = 0; tap < G::NT; ++tap, ++g) {
+                    // staggered prefetch of the next stage into the other buffer
+                    if (have_next) {
+                        const int cn = (st + 1) * G::CPS + c;
+                        if (cn < total_chunks) {
+                            if (tap == 0 && wave < 4) issue_chunk_dma<G::DPW>(chunk_base(s, cn, b, V), nxt + c * G::CH_BYTES, goff, loff);
+                            if (tap == (G::NT > 1 ? G::NT / 2 : 0) && wave >= 4)
+                                issue_chunk_dma<G::DPW>(chunk_base(s, cn, b, V), nxt + c * G::CH_BYTES, goff, loff);
+                        }
+                    }
+                    const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+                    half8 bc[NJ][2];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { bc[j][0] = bnx[j][0]; bc[j][1] = bnx[j][1]; }
+                    if (g + 1 < nsteps) {
+                        const char* wn_ = wuni + (int64_t)(g + 1) * bstep;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int kind = 0; kind < 2; ++kind)
+                                bnx[j][kind] = *reinterpret_cast<const half8*>(wn_ + kind * bkind + j * 512 + wlane);
+                    }
+                    half8 a[FM][2];
+#pragma unroll
+                    for (int f = 0; f < FM; ++f) {
+                        const int yo = (FM == 4) ? (f >> 1) : 0, zp = (FM == 4) ? (f & 1) : f;
+#pragma unroll
+                        for (int kind = 0; kind < 2; ++kind)
+                            a[f][kind] = *reinterpret_cast<const half8*>(
+                                A + (kind * 2 * G::PLANE + (2 * zp + dz) * G::PZ + (yo + dy) * G::SX + dx) * 16);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int f = 0; f < FM; ++f) {
+                            acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][1], bc[j][0], acc[f][j], 0, 0, 0);
+                            acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bc[j][1], acc[f][j], 0, 0, 0);
+                            acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bc[j][0], acc[f][j], 0, 0, 0);
+                        }
+                    // keep the unrolled taps in program order: without this hipcc hoists the B loads of many
+                    // future taps and spills (256 VGPRs + scratch)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();   // next stage landed (vmcnt drained) and everyone is done reading `cur`
+    }
+
+    const int col = lane & 31, rhalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nb * BN + wn * WNC + j * 32 + col;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int f = 0; f < FM; ++f) {
+            const int yo = (FM == 4) ? (f >> 1) : 0, zp = (FM == 4) ? (f & 1) : f;
+            const int gy = ty * 8 + y_w + yo;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (i & 3) + 8 * (i >> 2) + 4 * rhalf;
+                const int gx = tx * 16 + (r & 15), gz = tz * 4 + 2 * zp + (r >> 4);
+                if (gx < d.W && gy < d.H && gz < d.D)
+                    out[((int64_t)b * V + (int64_t)(gz * d.H + gy) * d.W + gx) * cout + n] = acc[f][j][i] * out_scale + bv;
+            }
+        }
+    }
+}
+
+template <int KS, int BN, int WM, int WN>
+static void launch_conv2_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
+                           float* out, int B, Dims d, int cout, hipStream_t st) {
+    using G = Geo2<KS>;
+    int total = 0;
+    for (int i = 0; i < s.n; ++i) total += s.chunks[i];
+    int ntx = (d.W + 15) / 16, nty = (d.H + 7) / 8, ntz = (d.D + 3) / 4, nnb = cout / BN;
+    size_t lds = 2 * G::STAGE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv2_kernel<KS, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(ntx * nty * ntz * nnb, B);
+    hipLaunchKernelGGL((conv2_kernel<KS, BN, WM, WN>), grid, dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
+                       cout, total, ntx, nty, nnb);
+}
+
+static int conv_impl() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MICA_CONV_IMPL");
+        v = (e && e[0] == '1') ? 1 : 2;
+    }
+    return v;
+}
+
 void launch_conv_mfma(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
                       float out_scale, float* out, int B, Dims d, int cout, int ksize, int* /*errflag*/,
                       hipStream_t st) {
     // cout is always a multiple of 32 here (small heads go through launch_head_final)
+    if (conv_impl() == 2) {
+        if (ksize == 3) {
+            if (cout % 128 == 0) launch_conv2_t<3, 128, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+            else if (cout % 64 == 0) launch_conv2_t<3, 64, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+            else launch_conv2_t<3, 32, 8, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        } else {
+            if (cout % 128 == 0) launch_conv2_t<1, 128, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+            else if (cout % 64 == 0) launch_conv2_t<1, 64, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+            else launch_conv2_t<1, 32, 8, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        }
+        return;
+    }
     if (ksize == 3) {
         if (cout % 128 == 0) launch_conv_t<3, 128>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
         else if (cout % 64 == 0) launch_conv_t<3, 64>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
