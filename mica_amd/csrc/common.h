@@ -84,9 +84,21 @@ int64_t stem_weight_floats();
 void launch_feat_gate(const float* x, int B, int V, const float* w0, const float* b0, const float* w2,
                       const float* b2, SplitView out, int* errflag, hipStream_t st);
 // head tail: raw2 [B][V][32] -> logits NCDHW [B][ncls][V] ; optional copy into split extras view at ch_off
+// extra_raw (nullable): also store the logits as channels [extra_ch_off, +ncls) of f32 [B][extra_raw_c][V]
 void launch_head_final(const float* x, int B, int V, const float* mean, const float* rstd, const float* gate,
                        const float* wf, const float* bf, int ncls, float* logits, SplitView extra,
-                       int extra_ch_off, hipStream_t st);
+                       int extra_ch_off, float* extra_raw, int extra_raw_c, hipStream_t st);
+// ---- Winograd F(2,3) along x (dense 3^3 convs): operand layout [B][chunks][4][Vh][2][16], Vh = D*H*ceil(W/2)
+void launch_prep_wino(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, int relu,
+                      const float* scale, SplitView wino, SplitView plain, float* gap, float* ws, int* errflag,
+                      hipStream_t st);
+void launch_prep_ncdhw_wino(const float* x, int B, Dims d, int C, SplitView wino, int* errflag, hipStream_t st);
+void launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
+                      float out_scale, float* out, int B, Dims d, int cout, hipStream_t st);
+void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_seg_c, const int* h_seg_cp, int nseg,
+                              const float* cin_scale, int B, float cout_scale, float wscale, _Float16* wpk,
+                              hipStream_t st);
+int64_t packed_weight_halves_wino(int cout, int total_chunks);
 void launch_postprocess(const float* bb, const float* ca, const float* aa, int B, int V, float* bbp, float* cap,
                         float* aap, float* aapred, hipStream_t st);
 void launch_fill_half(_Float16* p, int64_t n, hipStream_t st);

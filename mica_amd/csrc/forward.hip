@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -29,6 +30,7 @@ struct ConvLayer {
     float cout_scale = 1.f;           // folded output scale (FPN softmax weight, model.py:201-205)
     float wscale = 1.f;               // power of two bringing max|w| to ~4096 (f16 hi/lo stay normal)
     bool per_tile = false;            // weights re-packed per tile with a gate folded in (cin_scale)
+    bool wino = false;                // 3^3 conv on the Winograd F(2,3)-along-x path
     float* d_w = nullptr;             // torch layout f32
     float* d_b = nullptr;             // bias (already times cout_scale)
     _Float16* d_wpk = nullptr;        // packed (static) or per-tile buffer [maxB][...]
@@ -78,7 +80,10 @@ struct mica_ctx {
     Head heads[3];
 
     // activations
-    _Float16 *S_exp, *S_af, *S_fw, *S_x0, *S_1, *S_2, *S_3, *S_dw, *S_f, *S_c[3], *S_l, *S_fpn, *S_extra, *S_h1;
+    // operands of 3^3 convs are in wino layout (2x bytes) when `wino`, else plain split; S_cp = plain copies for the 1x1 laterals
+    _Float16 *S_exp, *S_af, *S_fw, *S_x0, *S_1, *S_2, *S_3, *S_dw, *S_f, *S_c[3], *S_cp[3], *S_l, *S_fpn, *S_extra, *S_h1;
+    float* extra_raw = nullptr;   // [B][8][V] backbone + CA logits (NCDHW) feeding the next heads' conv1
+    bool wino = true;
     float *R_a, *R_b, *R_c;
     float *logits[3];             // internal NCDHW logits when the caller wants probabilities only
     float* ws = nullptr;          // reduction partials
@@ -179,13 +184,17 @@ int setup_conv(mica_ctx* c, ConvLayer& L, const std::string& name, int cout, int
     for (float& v : bs) v *= cout_scale;
     r = upload(c, &L.d_b, bs);
     if (r) return r;
-    L.pk_halves = packed_weight_halves(cout, k, L.total_chunks);
+    L.wino = (k == 3) && c->wino;
+    L.pk_halves = L.wino ? packed_weight_halves_wino(cout, L.total_chunks) : packed_weight_halves(cout, k, L.total_chunks);
     r = dalloc(c, &L.d_wpk, L.pk_halves * (per_tile ? c->maxB : 1));
     if (r) return r;
     if (per_tile) {
         r = dalloc(c, &L.d_cin_scale, (int64_t)c->maxB * L.cin);
         if (r) return r;
         launch_fill_float(L.d_cin_scale, (int64_t)c->maxB * L.cin, 1.0f, 0);
+    } else if (L.wino) {
+        launch_pack_weights_wino(L.d_w, cout, L.cin, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(), nullptr, 1, cout_scale,
+                                 L.wscale, L.d_wpk, 0);
     } else {
         launch_pack_weights(L.d_w, cout, L.cin, k, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(), nullptr, 1,
                             cout_scale, L.wscale, L.d_wpk, 0);
@@ -233,8 +242,11 @@ void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, 
         e0 = c->ev[c->ev_used++]; e1 = c->ev[c->ev_used++];
         hipEventRecord(e0, st);
     }
-    launch_conv_mfma(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
-                     L.k, c->d_err, st);
+    if (L.wino)
+        launch_conv_wino(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout, st);
+    else
+        launch_conv_mfma(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
+                         L.k, c->d_err, st);
     if (c->profiling) {
         hipEventRecord(e1, st);
         c->prof_flops += L.flops_per_voxel * (double)c->V * B;
@@ -244,6 +256,20 @@ void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, 
 void gate(mica_ctx* c, const GateMLP& g, const float* pool, const float* premul, int B, const float* postmul, float* out,
           float* out_post, int post_stride, hipStream_t st) {
     launch_gate_mlp(pool, premul, B, g.C, g.Ch, g.w1, g.b1, g.w2, g.b2, postmul, out, out_post, post_stride, st);
+}
+
+// Re-encode a raw conv output as the operand(s) of its consumers: `t3` feeds 3^3 convs (wino layout when the
+// Winograd path is on, else plain split), `t1` feeds 1x1 convs (always plain split).  Either may be empty.
+void make_operand(mica_ctx* c, const float* raw, int B, int C, const float* mean, const float* rstd, int relu, SplitView t3,
+                  SplitView t1, float* gap, hipStream_t st) {
+    if (c->wino && t3.p) {
+        launch_prep_wino(raw, B, c->d, C, mean, rstd, relu, nullptr, t3, t1, gap, c->ws, c->d_err, st);
+    } else {
+        SplitView o = t3.p ? t3 : t1;
+        launch_prep(raw, B, c->V, C, mean, rstd, relu, nullptr, o, nullptr, gap, c->ws, c->d_err, st);
+        if (t3.p && t1.p && t1.p != t3.p)
+            launch_prep(raw, B, c->V, C, mean, rstd, relu, nullptr, t1, nullptr, nullptr, c->ws, c->d_err, st);
+    }
 }
 
 // One run of tiles that share the AF branch (model.py:56-74).  Workspace slots 0..B-1.
@@ -259,12 +285,13 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         run_conv(c, c->downsizing, SrcList().add(c->S_exp, 8, 0, 8), c->R_a, B, st);
     } else {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->fusion0.d_cin_scale, 192, st);
-        launch_prep_ncdhw(d_af, B, V, 24, view(c->S_af, 2, 0, 2), nullptr, c->d_err, st);
+        if (c->wino) launch_prep_ncdhw_wino(d_af, B, d, 24, view(c->S_af, 2, 0, 2), c->d_err, st);
+        else launch_prep_ncdhw(d_af, B, V, 24, view(c->S_af, 2, 0, 2), nullptr, c->d_err, st);
         run_conv(c, c->feat_conv, SrcList().add(c->S_af, 2, 0, 2), c->R_b, B, st);
         launch_feat_gate(c->R_b, B, V, c->fg_w0, c->fg_b0, c->fg_w2, c->fg_b2, view(c->S_fw, 4, 0, 4), c->d_err, st);
         run_conv(c, c->fusion0, SrcList().add(c->S_exp, 8, 0, 8).add(c->S_fw, 4, 0, 4), c->R_a, B, st);
     }
-    launch_prep(c->R_a, B, V, 64, nullptr, nullptr, 0, nullptr, view(c->S_x0, 4, 0, 4), nullptr, nullptr, c->ws, c->d_err, st);
+    make_operand(c, c->R_a, B, 64, nullptr, nullptr, 0, view(c->S_x0, 4, 0, 4), none, nullptr, st);
 
     // ---- encoders (model.py:149-152) -----------------------------------------------------------
     const _Float16* X = c->S_x0;
@@ -274,39 +301,41 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         // ResidualDenseBlock (model.py:130-134)
         run_conv(c, E.conv1, SrcList().add(X, cc, 0, cc), c->R_a, B, st);
         launch_stats(c->R_a, B, V, C / 2, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
-        launch_prep(c->R_a, B, V, C / 2, c->v_mean, c->v_rstd, 1, nullptr, view(c->S_1, ch, 0, ch), nullptr, nullptr, c->ws, c->d_err, st);
+        make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_1, ch, 0, ch), none, nullptr, st);
         run_conv(c, E.conv2, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch), c->R_a, B, st);
         launch_stats(c->R_a, B, V, C / 2, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
-        launch_prep(c->R_a, B, V, C / 2, c->v_mean, c->v_rstd, 1, nullptr, view(c->S_2, ch, 0, ch), nullptr, nullptr, c->ws, c->d_err, st);
+        make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_2, ch, 0, ch), none, nullptr, st);
         run_conv(c, E.conv3, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch).add(c->S_2, ch, 0, ch), c->R_b, B, st);
         launch_stats(c->R_b, B, V, C, 1e-5f, c->v_mean3, c->v_rstd3, c->ws, st);
-        launch_prep(c->R_b, B, V, C, c->v_mean3, c->v_rstd3, 1, nullptr, view(c->S_3, cc, 0, cc), nullptr, c->v_pool, c->ws, c->d_err, st);
+        make_operand(c, c->R_b, B, C, c->v_mean3, c->v_rstd3, 1, none, view(c->S_3, cc, 0, cc), c->v_pool, st);
         // SEBlock gate (model.py:254-258); applied downstream: folded into the depthwise load and the fusion weights
         gate(c, E.se, c->v_pool, nullptr, B, nullptr, c->v_gse, nullptr, 0, st);
         // DualAttention (model.py:98-101): local branch
         launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, c->v_gse, E.dw_w, E.dw_b, c->R_c, st);
         launch_stats(c->R_c, B, V, C, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
-        launch_prep(c->R_c, B, V, C, c->v_mean, c->v_rstd, 1, nullptr, view(c->S_dw, cc, 0, cc), nullptr, nullptr, c->ws, c->d_err, st);
+        make_operand(c, c->R_c, B, C, c->v_mean, c->v_rstd, 1, none, view(c->S_dw, cc, 0, cc), nullptr, st);
         // global branch: GAP(se(x3)) = g_se * GAP(x3); global_feat = g_ga * g_se * x3 folded into fusion's weights
         gate(c, E.ga, c->v_pool, c->v_gse, B, c->v_gse, nullptr, E.fusion.d_cin_scale + C, 2 * C, st);
         run_conv(c, E.fusion, SrcList().add(c->S_dw, cc, 0, cc).add(c->S_3, cc, 0, cc), c->R_a, B, st);
-        launch_prep(c->R_a, B, V, C, nullptr, nullptr, 0, nullptr, view(c->S_f, cc, 0, cc), nullptr, nullptr, c->ws, c->d_err, st);
-        // transition (model.py:141-147)
+        make_operand(c, c->R_a, B, C, nullptr, nullptr, 0, view(c->S_f, cc, 0, cc), none, nullptr, st);
+        // transition (model.py:141-147); c_e feeds the next encoder's 3^3 convs and the FPN's 1x1 lateral
         run_conv(c, E.transition, SrcList().add(c->S_f, cc, 0, cc), c->R_a, B, st);
         launch_stats(c->R_a, B, V, 2 * C, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
-        launch_prep(c->R_a, B, V, 2 * C, c->v_mean, c->v_rstd, 1, nullptr, view(c->S_c[e], 2 * cc, 0, 2 * cc), nullptr, nullptr, c->ws, c->d_err, st);
+        make_operand(c, c->R_a, B, 2 * C, c->v_mean, c->v_rstd, 1, e < 2 ? view(c->S_c[e], 2 * cc, 0, 2 * cc) : none,
+                     view(c->S_cp[e], 2 * cc, 0, 2 * cc), nullptr, st);
         X = c->S_c[e];
     }
     // ---- FPN (model.py:182-205; the interpolations are identities) ------------------------------
     for (int i = 0; i < 3; ++i) {
         const int cc = (128 << i) / 16;
-        run_conv(c, c->lateral[i], SrcList().add(c->S_c[i], cc, 0, cc), c->R_a, B, st);
-        launch_prep(c->R_a, B, V, 64, nullptr, nullptr, 0, nullptr, view(c->S_l, 4, 0, 4), nullptr, nullptr, c->ws, c->d_err, st);
+        run_conv(c, c->lateral[i], SrcList().add(c->S_cp[i], cc, 0, cc), c->R_a, B, st);
+        make_operand(c, c->R_a, B, 64, nullptr, nullptr, 0, view(c->S_l, 4, 0, 4), none, nullptr, st);
         run_conv(c, c->smooth[i], SrcList().add(c->S_l, 4, 0, 4), c->R_b, B, st);
-        launch_prep(c->R_b, B, V, 64, nullptr, nullptr, 0, nullptr, view(c->S_fpn, 12, 4 * i, 4), nullptr, nullptr, c->ws, c->d_err, st);
+        make_operand(c, c->R_b, B, 64, nullptr, nullptr, 0, view(c->S_fpn, 12, 4 * i, 4), none, nullptr, st);
     }
     // ---- heads (model.py:230-239, 344-346) ------------------------------------------------------
-    launch_fill_half(c->S_extra, (int64_t)B * V * 32, st);
+    if (c->wino) hipMemsetAsync(c->extra_raw, 0, sizeof(float) * (size_t)B * 8 * V, st);
+    else launch_fill_half(c->S_extra, (int64_t)B * V * 32, st);
     float* outs[3] = {o_bb, o_ca, o_aa};
     for (int h = 0; h < 3; ++h) {
         Head& H = c->heads[h];
@@ -315,13 +344,16 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         if (h > 0) src.add(c->S_extra, 1, 0, 1);
         run_conv(c, H.conv1, src, c->R_a, B, st);
         launch_stats(c->R_a, B, V, 64, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
-        launch_prep(c->R_a, B, V, 64, c->v_mean, c->v_rstd, 1, nullptr, view(c->S_h1, 4, 0, 4), nullptr, nullptr, c->ws, c->d_err, st);
+        make_operand(c, c->R_a, B, 64, c->v_mean, c->v_rstd, 1, view(c->S_h1, 4, 0, 4), none, nullptr, st);
         run_conv(c, H.conv2, SrcList().add(c->S_h1, 4, 0, 4), c->R_b, B, st);
         launch_stats(c->R_b, B, V, 32, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
         launch_prep(c->R_b, B, V, 32, c->v_mean, c->v_rstd, 1, nullptr, none, nullptr, c->v_pool, c->ws, c->d_err, st);
         gate(c, H.cal, c->v_pool, nullptr, B, nullptr, c->v_gate, nullptr, 0, st);
+        const bool feeds = h < 2;
         launch_head_final(c->R_b, B, V, c->v_mean, c->v_rstd, c->v_gate, H.wf, H.bf, H.ncls, outs[h],
-                          h < 2 ? view(c->S_extra, 1, 0, 1) : none, 4 * h, st);
+                          (feeds && !c->wino) ? view(c->S_extra, 1, 0, 1) : none, 4 * h, (feeds && c->wino) ? c->extra_raw : nullptr,
+                          8, st);
+        if (feeds && c->wino) launch_prep_ncdhw_wino(c->extra_raw, B, d, 8, view(c->S_extra, 1, 0, 1), c->d_err, st);
     }
     return MICA_OK;
 }
@@ -428,11 +460,22 @@ int mica_create(int device, int max_batch, int tile_size, mica_ctx** out) {
     c->V = tile_size * tile_size * tile_size;
     const int64_t BV = (int64_t)max_batch * c->V;
     int r = 0;
-    auto S = [&](_Float16** p, int ch) { if (!r) r = dalloc(c, p, BV * ch * 2); };   // hi + lo
-    S(&c->S_exp, 128); S(&c->S_af, 32); S(&c->S_fw, 64); S(&c->S_x0, 64);
-    S(&c->S_1, 128); S(&c->S_2, 128); S(&c->S_3, 256); S(&c->S_dw, 256); S(&c->S_f, 256);
-    S(&c->S_c[0], 128); S(&c->S_c[1], 256); S(&c->S_c[2], 512);
-    S(&c->S_l, 64); S(&c->S_fpn, 192); S(&c->S_extra, 16); S(&c->S_h1, 64);
+    {
+        const char* e = getenv("MICA_WINO");
+        c->wino = !(e && e[0] == '0');
+    }
+    // wino layout holds 4 transformed values per output pair: 2x the plain bytes (pairs = ceil(W/2) per row)
+    const int64_t BVw = (int64_t)max_batch * tile_size * tile_size * ((tile_size + 1) / 2) * 4;
+    auto S = [&](_Float16** p, int ch) { if (!r) r = dalloc(c, p, BV * ch * 2); };                        // plain: hi + lo
+    auto W3 = [&](_Float16** p, int ch) { if (!r) r = dalloc(c, p, (c->wino ? BVw : BV) * ch * 2); };      // operand of 3^3 convs
+    S(&c->S_exp, 128); W3(&c->S_af, 32); S(&c->S_fw, 64); W3(&c->S_x0, 64);
+    W3(&c->S_1, 128); W3(&c->S_2, 128); S(&c->S_3, 256); S(&c->S_dw, 256); W3(&c->S_f, 256);
+    W3(&c->S_c[0], 128); W3(&c->S_c[1], 256); c->S_c[2] = nullptr;
+    if (c->wino) { S(&c->S_cp[0], 128); S(&c->S_cp[1], 256); }
+    S(&c->S_cp[2], 512);
+    if (!c->wino) { c->S_cp[0] = c->S_c[0]; c->S_cp[1] = c->S_c[1]; }
+    W3(&c->S_l, 64); W3(&c->S_fpn, 192); W3(&c->S_extra, 16); W3(&c->S_h1, 64);
+    if (!r) r = dalloc(c, &c->extra_raw, BV * 8);
     auto R = [&](float** p, int ch) { if (!r) r = dalloc(c, p, BV * ch); };
     R(&c->R_a, 512); R(&c->R_b, 256); R(&c->R_c, 256);
     R(&c->logits[0], 4); R(&c->logits[1], 4); R(&c->logits[2], 21);
@@ -685,12 +728,14 @@ int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int
     HIPC(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const int V = d * h * w, cp = pad16(cin), nt = k * k * k;
+    const bool wino = (k == 3) && c->wino;
+    const int64_t Vop = wino ? (int64_t)d * h * ((w + 1) / 2) * 4 : V;
     Tmp t;
-    _Float16* sx = t.get<_Float16>((int64_t)batch * V * cp * 2);
+    _Float16* sx = t.get<_Float16>((int64_t)batch * Vop * cp * 2);
     float* dw = t.get<float>((int64_t)cout * cin * nt);
     float* db = t.get<float>(cout);
     float* raw = t.get<float>((int64_t)batch * V * cout);
-    _Float16* pk = t.get<_Float16>(packed_weight_halves(cout, k, cp / 16));
+    _Float16* pk = t.get<_Float16>(wino ? packed_weight_halves_wino(cout, cp / 16) : packed_weight_halves(cout, k, cp / 16));
     int* derr = t.get<int>(1);
     if (!sx || !dw || !db || !raw || !pk || !derr) { c->err = "mica_op_conv3d: hipMalloc failed"; return MICA_ERR_HIP; }
     std::vector<float> hw(h_w, h_w + (size_t)cout * cin * nt);
@@ -698,12 +743,18 @@ int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int
     HIPC(c, hipMemcpyAsync(dw, h_w, sizeof(float) * cout * cin * nt, hipMemcpyHostToDevice, st));
     HIPC(c, hipMemcpyAsync(db, h_b, sizeof(float) * cout, hipMemcpyHostToDevice, st));
     HIPC(c, hipMemsetAsync(derr, 0, 4, st));
-    launch_prep_ncdhw(d_x, batch, V, cin, SplitView{sx, cp / 16, 0, cp / 16}, nullptr, derr, st);
     int sc[1] = {cin}, scp[1] = {cp};
-    launch_pack_weights(dw, cout, cin, k, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
     ConvSrcs s{};
     s.n = 1; s.p[0] = sx; s.chunks_total[0] = cp / 16; s.chunk_off[0] = 0; s.chunks[0] = cp / 16;
-    launch_conv_mfma(s, pk, 0, db, 1.0f / (ws * ASCALE), raw, batch, Dims{d, h, w}, cout, k, derr, st);
+    if (wino) {
+        launch_prep_ncdhw_wino(d_x, batch, Dims{d, h, w}, cin, SplitView{sx, cp / 16, 0, cp / 16}, derr, st);
+        launch_pack_weights_wino(dw, cout, cin, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
+        launch_conv_wino(s, pk, 0, db, 1.0f / (ws * ASCALE), raw, batch, Dims{d, h, w}, cout, st);
+    } else {
+        launch_prep_ncdhw(d_x, batch, V, cin, SplitView{sx, cp / 16, 0, cp / 16}, nullptr, derr, st);
+        launch_pack_weights(dw, cout, cin, k, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
+        launch_conv_mfma(s, pk, 0, db, 1.0f / (ws * ASCALE), raw, batch, Dims{d, h, w}, cout, k, derr, st);
+    }
     launch_nhwc_to_nchw(raw, batch, cout, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));

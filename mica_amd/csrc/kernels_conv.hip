@@ -9,6 +9,8 @@
 
 namespace mica {
 
+struct Segs { int c[MAX_SRC]; int cp[MAX_SRC]; int n; };   // channel segmentation of a conv's concatenated input
+
 // ------------------------------------------------------------------------------------------------
 // Geometry of one workgroup (256 threads = 4 waves): output tile 16(x) x 8(y) x 2(z) voxels = 256 GEMM
 // rows, BN output channels.  Wave w owns rows y = 2w, 2w+1; an MFMA row-fragment (32 rows) is the 16 x
@@ -430,6 +432,282 @@ static void launch_conv2_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_b
                        cout, total, ntx, nty, nnb);
 }
 
+
+// ================================================================================================
+// conv_wino: dense 3x3x3 conv with Winograd F(2,3) along x on top of the conv2 structure.  The kernel is
+// power/MFMA-issue bound (1.25 PF of f16 MFMA measured), so the lever left is fewer MFMAs: per output pair
+// 4 transform-domain products replace 6 taps => 9 (dz,dy) taps x 4 positions instead of 27 taps x 2 outputs
+// = 1.5x fewer MFMAs for the same result (products stay split-f16, accumulate f32; the transforms are
+// +-1 / 0.5 combinations done in f32 by the producer (prep_wino) and the weight packer).
+//   y[2i]   = m0 + m1 + m2          m_p = sum_{dz,dy,cin} t_p * u_p
+//   y[2i+1] = m1 - m2 - m3          u0 = g0, u1 = (g0+g1+g2)/2, u2 = (g0-g1+g2)/2, u3 = g2
+// Workgroup: 8 waves, output tile 16(x) = 8 pairs x 4(y) x 4(z); wave (p, wn) owns Winograd position p for
+// all 128 (pair,y,z) rows and 64 (BN/2) channels.  LDS image per chunk: 4 planes (hi/lo x k-half) x
+// [z 6][p 4][y 6][pair 8] 16-B slots = 73,728 B, double buffered, filled by LDS-DMA; a row fragment is
+// (8 pairs x 4 y) of one z: y rows are 8 slots apart => every ds_read_b128 lane group covers 16 distinct slots.
+// Epilogue: the four position-waves exchange their accumulators through LDS and apply the output transform.
+// ================================================================================================
+struct GeoW {
+    static constexpr int SY = 6, SZ = 6;
+    static constexpr int PP = SY * 8;               // slots per (z, p)
+    static constexpr int PZ = 4 * PP;               // 192 slots per z plane = 3 DMA instructions
+    static constexpr int PLANE = SZ * PZ;           // 1152
+    static constexpr int CH_BYTES = 4 * PLANE * 16; // 73,728
+    static constexpr int NT = 9;
+    static constexpr int DPZ = PZ / 64;
+    static constexpr int DMA_PER_CHUNK = 4 * SZ * DPZ;   // 72
+    static constexpr int DPW = DMA_PER_CHUNK / 8;        // 9
+};
+
+__device__ __forceinline__ const _Float16* chunk_base_wino(const ConvSrcs& s, int gch, int b, int Vh) {
+    int si = 0, ch = gch;
+#pragma unroll
+    for (int i = 0; i < MAX_SRC - 1; ++i)
+        if (si == i && i + 1 < s.n && ch >= s.chunks[i]) { ch -= s.chunks[i]; si = i + 1; }
+    return s.p[si] + ((int64_t)b * s.chunks_total[si] + s.chunk_off[si] + ch) * (int64_t)Vh * 128;
+}
+
+template <int BN, int WN>
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
+                                                           const float* __restrict__ bias, float out_scale,
+                                                           float* __restrict__ out, Dims d, int cout, int total_chunks,
+                                                           int ntx, int nty, int nnb) {
+    using G = GeoW;
+    constexpr int WM = 8 / WN;                     // 4 (positions) when WN = 2 ; WN = 1 => 8 waves = 4 positions x 2 z-halves
+    constexpr int FM = (WN == 2) ? 4 : 2;          // z fragments per wave
+    constexpr int WNC = (WN == 2) ? BN / 2 : BN;
+    constexpr int NJ = WNC / 32;
+    static_assert(NJ >= 1, "wave tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 3;                                   // Winograd position of this wave
+    const int wn = (WN == 2) ? (wave >> 2) : 0;
+    const int zf0 = (WN == 2) ? 0 : (wave >> 2) * 2;           // first z fragment
+    const int b = blockIdx.y;
+    const int Wh = (d.W + 1) >> 1;
+    const int V = d.D * d.H * d.W, Vh = d.D * d.H * Wh;
+
+    int id = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
+    const int nb = id % nnb;
+    const int tile = id / nnb;
+    const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+    const int i0 = tx * 8, y0 = ty * 4 - 1, z0 = tz * 4 - 1;
+
+    for (int i = tid; i < 2 * G::CH_BYTES / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+    int goff[G::DPW], loff[G::DPW];
+#pragma unroll
+    for (int k = 0; k < G::DPW; ++k) {
+        const int ii = wave * G::DPW + k;
+        const int q = ii / (G::SZ * G::DPZ), rem = ii % (G::SZ * G::DPZ);
+        const int vz = rem / G::DPZ, part = rem % G::DPZ;
+        const int slot = part * 64 + lane;                       // within the z plane: [p][y][pair]
+        const int pp = slot / G::PP, r2 = slot - pp * G::PP;
+        const int vy = r2 >> 3, pr = r2 & 7;
+        const int gi = i0 + pr, gy = y0 + vy, gz = z0 + vz;
+        const bool ok = gi < Wh && (unsigned)gy < (unsigned)d.H && (unsigned)gz < (unsigned)d.D;
+        goff[k] = ok ? (pp * Vh + (gz * d.H + gy) * Wh + gi) * 32 + q * 8 : -1;
+        loff[k] = (q * G::PLANE + vz * G::PZ + part * 64) * 16;
+    }
+
+    floatx16 acc[FM][NJ];
+#pragma unroll
+    for (int f = 0; f < FM; ++f)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[f][j][i] = 0.f;
+
+    const int lx = lane & 7, ly = (lane >> 3) & 3, lh = lane >> 5;
+    const int a_base = (lh * G::PLANE + zf0 * G::PZ + wp * G::PP + ly * 8 + lx) * 16;
+    // packed weights: [chunk][tap 9][p 4][q 4][cout][8] halves
+    const int64_t pstride = (int64_t)4 * cout * 16;
+    const int64_t bstep = 4 * pstride;
+    const int64_t bkind = (int64_t)2 * cout * 16;
+    const char* wuni = reinterpret_cast<const char*>(wpk + (int64_t)b * wpk_bstride) + wp * pstride + (int64_t)(nb * BN + wn * WNC) * 16;
+    const unsigned wlane = (unsigned)(lh * cout + (lane & 31)) * 16u;
+
+    const int nsteps = total_chunks * G::NT;
+    half8 bnx[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) bnx[j][kind] = *reinterpret_cast<const half8*>(wuni + kind * bkind + j * 512 + wlane);
+
+    __syncthreads();
+    issue_chunk_dma<G::DPW>(chunk_base_wino(s, 0, b, Vh), smem, goff, loff);
+    __syncthreads();
+
+    int g = 0;
+    for (int gch = 0; gch < total_chunks; ++gch) {
+        const char* A = smem + (gch & 1) * G::CH_BYTES + a_base;
+        char* nxt = smem + ((gch + 1) & 1) * G::CH_BYTES;
+        const bool have_next = gch + 1 < total_chunks;
+#pragma unroll
+        for (int tap = 0; tap < G::NT; ++tap, ++g) {
+            if (have_next) {
+                if (tap == 0 && wave < 4) issue_chunk_dma<G::DPW>(chunk_base_wino(s, gch + 1, b, Vh), nxt, goff, loff);
+                if (tap == 4 && wave >= 4) issue_chunk_dma<G::DPW>(chunk_base_wino(s, gch + 1, b, Vh), nxt, goff, loff);
+            }
+            const int dz = tap / 3, dy = tap % 3;
+            half8 bc[NJ][2];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { bc[j][0] = bnx[j][0]; bc[j][1] = bnx[j][1]; }
+            if (g + 1 < nsteps) {
+                const char* wn_ = wuni + (int64_t)(g + 1) * bstep;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int kind = 0; kind < 2; ++kind)
+                        bnx[j][kind] = *reinterpret_cast<const half8*>(wn_ + kind * bkind + j * 512 + wlane);
+            }
+            half8 a[FM][2];
+#pragma unroll
+            for (int f = 0; f < FM; ++f)
+#pragma unroll
+                for (int kind = 0; kind < 2; ++kind)
+                    a[f][kind] = *reinterpret_cast<const half8*>(A + (kind * 2 * G::PLANE + (f + dz) * G::PZ + dy * 8) * 16);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int f = 0; f < FM; ++f) {
+                    acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][1], bc[j][0], acc[f][j], 0, 0, 0);
+                    acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bc[j][1], acc[f][j], 0, 0, 0);
+                    acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bc[j][0], acc[f][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- output transform through LDS: region [wn][zfrag 4][p 4][row 32][col 32] floats per j -------
+    float* xs = reinterpret_cast<float*>(smem);
+    const int col = lane & 31, rhalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int f = 0; f < FM; ++f) {
+            float* dst = xs + ((((wn * 4 + zf0 + f) * 4 + wp) * 32) * 32);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (i & 3) + 8 * (i >> 2) + 4 * rhalf;
+                dst[r * 32 + col] = acc[f][j][i];
+            }
+        }
+        __syncthreads();
+        // 8 waves x FM z-fragments... each wave finishes (wn, z) pairs: WN=2: wave (wp, wn) -> z = wp ; WN=1: wave -> z = wave>>1, half rows
+        {
+            const int zz = (WN == 2) ? wp : (wave >> 1);
+            const int r_lo = (WN == 2) ? 0 : (wave & 1) * 16, r_n = (WN == 2) ? 32 : 16;
+            const float* src = xs + ((wn * 4 + zz) * 4) * 1024;
+            const int n = nb * BN + wn * WNC + j * 32 + col;
+            const float bv = bias ? bias[n] : 0.f;
+            const int gz = tz * 4 + zz;
+            for (int rr = rhalf; rr < r_n; rr += 2) {
+                const int r = r_lo + rr;
+                const float m0 = src[0 * 1024 + r * 32 + col], m1 = src[1 * 1024 + r * 32 + col];
+                const float m2 = src[2 * 1024 + r * 32 + col], m3 = src[3 * 1024 + r * 32 + col];
+                const int pr = r & 7, yy = r >> 3;
+                const int gx = (i0 + pr) * 2, gy = ty * 4 + yy;
+                if (gy < d.H && gz < d.D) {
+                    float* o = out + ((int64_t)b * V + (int64_t)(gz * d.H + gy) * d.W + gx) * cout + n;
+                    if (gx < d.W) o[0] = (m0 + m1 + m2) * out_scale + bv;
+                    if (gx + 1 < d.W) o[cout] = (m1 - m2 - m3) * out_scale + bv;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int BN, int WN>
+static void launch_conv_wino_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
+                               float* out, int B, Dims d, int cout, hipStream_t st) {
+    int total = 0;
+    for (int i = 0; i < s.n; ++i) total += s.chunks[i];
+    int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / BN;
+    size_t lds = 2 * GeoW::CH_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(ntx * nty * ntz * nnb, B);
+    hipLaunchKernelGGL((conv_wino_kernel<BN, WN>), grid, dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout,
+                       total, ntx, nty, nnb);
+}
+
+void launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
+                      float* out, int B, Dims d, int cout, hipStream_t st) {
+    if (cout % 128 == 0) launch_conv_wino_t<128, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+    else if (cout % 64 == 0) launch_conv_wino_t<64, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+    else launch_conv_wino_t<32, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+}
+
+// weights for conv_wino: [B][chunk][tap 9 = (dz,dy)][p 4][q 4][Cout][8] halves, u = G g along kw
+__global__ void pack_weights_wino_kernel(const float* __restrict__ w, int cout, int cin, Segs sg, int total_chunks,
+                                         const float* __restrict__ cin_scale, float mul, _Float16* __restrict__ wpk,
+                                         int64_t per_b) {
+    const int b = blockIdx.y;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [chunk][tap][p][q][n]
+    int64_t total = (int64_t)total_chunks * 9 * 4 * 4 * cout;
+    if (e >= total) return;
+    int n = e % cout;
+    int q = (e / cout) & 3;
+    int pp = (e / ((int64_t)cout * 4)) & 3;
+    int tap = (e / ((int64_t)cout * 16)) % 9;
+    int gch = e / ((int64_t)cout * 16 * 9);
+    int kind = q >> 1, kh = q & 1;
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int kp = gch * 16 + kh * 8 + j;
+        int ci = -1, accp = 0, accc = 0;
+        for (int si = 0; si < sg.n; ++si) {
+            if (kp >= accp && kp < accp + sg.cp[si]) {
+                int local = kp - accp;
+                if (local < sg.c[si]) ci = accc + local;
+            }
+            accp += sg.cp[si];
+            accc += sg.c[si];
+        }
+        float v = 0.f;
+        if (ci >= 0) {
+            const float* g = w + ((int64_t)n * cin + ci) * 27 + tap * 3;   // [dz][dy][dx]
+            float g0 = g[0], g1 = g[1], g2 = g[2];
+            float u = pp == 0 ? g0 : pp == 1 ? 0.5f * (g0 + g1 + g2) : pp == 2 ? 0.5f * (g0 - g1 + g2) : g2;
+            v = u * mul;
+            if (cin_scale) v *= cin_scale[(int64_t)b * cin + ci];
+        }
+        _Float16 hi = (_Float16)v;
+        _Float16 lo = (_Float16)(v - (float)hi);
+        o[j] = kind ? lo : hi;
+    }
+    *reinterpret_cast<half8*>(wpk + (int64_t)b * per_b + e * 8) = o;
+}
+
+int64_t packed_weight_halves_wino(int cout, int total_chunks) { return (int64_t)total_chunks * 9 * 16 * cout * 8; }
+
+void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_seg_c, const int* h_seg_cp, int nseg,
+                              const float* cin_scale, int B, float cout_scale, float wscale, _Float16* wpk, hipStream_t st) {
+    Segs sg;
+    sg.n = nseg;
+    int total_chunks = 0;
+    for (int i = 0; i < nseg; ++i) {
+        sg.c[i] = h_seg_c[i];
+        sg.cp[i] = h_seg_cp[i];
+        total_chunks += h_seg_cp[i] / 16;
+    }
+    int64_t total = (int64_t)total_chunks * 9 * 16 * cout;
+    dim3 grid((unsigned)((total + 255) / 256), B);
+    hipLaunchKernelGGL(pack_weights_wino_kernel, grid, dim3(256), 0, st, w, cout, cin, sg, total_chunks, cin_scale,
+                       cout_scale * wscale, wpk, packed_weight_halves_wino(cout, total_chunks));
+}
+
 static int conv_impl() {
     static int v = -1;
     if (v < 0) {
@@ -470,7 +748,6 @@ void launch_conv_mfma(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstrid
 // Weight packing: torch [Cout][Cin][k][k][k] f32 -> [B][chunk][tap][q][Cout][8] halves, q = kind*2+khalf.
 // Input channels are laid out as the concatenation of the conv's sources, each padded to 16.
 // ------------------------------------------------------------------------------------------------
-struct Segs { int c[MAX_SRC]; int cp[MAX_SRC]; int n; };
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int nt, Segs sg,
                                     int total_chunks, const float* __restrict__ cin_scale, float mul,

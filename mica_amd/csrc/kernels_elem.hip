@@ -241,6 +241,160 @@ void launch_prep(const float* x, int B, int V, int C, const float* mean, const f
     if (gap) launch_finalize_sum(ws, B, nblk, C, 1.0f / (float)V, gap, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// prep for Winograd F(2,3) convs: the same y = relu?((x-mean)*rstd)*scale, written as the x-direction
+// input transform of each output pair (x = 2i, 2i+1):  with d_k = y(2i-1+k), zero outside the volume,
+//   t0 = d0 - d2,  t1 = d1 + d2,  t2 = d2 - d1,  t3 = d1 - d3
+// in "wino" layout  _Float16 [B][chunks][4 (p)][Vh][2][16],  Vh = D*H*ceil(W/2)  (2x the plain bytes).
+// Thread = (8-channel group, pair); its own voxels are d1, d2 (plain / raw / gap outputs use those).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict__ x, Dims d, int C,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        int relu, const float* __restrict__ scale, SplitView wino,
+                                                        SplitView plain, float* __restrict__ ws, int* __restrict__ errflag) {
+    extern __shared__ float sh[];
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int G = C >> 3, SUB = 256 / G;
+    const int tid = threadIdx.x, g = tid % G, sub = tid / G;
+    const int Wh = (d.W + 1) >> 1;
+    const int V = d.D * d.H * d.W, Vh = d.D * d.H * Wh;
+    const int per = (Vh + nblk - 1) / nblk;
+    const int p0 = blk * per, p1 = min(Vh, p0 + per);
+    float m[8], r[8], sc[8], acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t ci = (int64_t)b * C + g * 8 + j;
+        m[j] = mean ? mean[ci] : 0.f;
+        r[j] = rstd ? rstd[ci] : 1.f;
+        sc[j] = scale ? scale[ci] : 1.f;
+        acc[j] = 0.f;
+    }
+    bool bad = false;
+    const float* xb = x + (int64_t)b * V * C + g * 8;
+    _Float16* wb = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + (g >> 1)) * 4 * Vh) * 32 + (g & 1) * 8;
+    _Float16* pb = plain.p ? plain.p + (((int64_t)b * plain.chunks_total + plain.chunk_off + (g >> 1)) * V) * 32 + (g & 1) * 8 : nullptr;
+    for (int ph = p0 + sub; ph < p1; ph += SUB) {
+        const int row = ph / Wh, i = ph - row * Wh;
+        const int xo = 2 * i;
+        float dv[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = xo - 1 + k;
+            const bool ok = (unsigned)xx < (unsigned)d.W;
+            const int xc = ok ? xx : xo;
+            float4 a = *reinterpret_cast<const float4*>(xb + ((int64_t)row * d.W + xc) * C);
+            float4 c = *reinterpret_cast<const float4*>(xb + ((int64_t)row * d.W + xc) * C + 4);
+            float y[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = (y[j] - m[j]) * r[j];
+                if (relu) t = fmaxf(t, 0.f);
+                dv[k][j] = ok ? t * sc[j] : 0.f;
+            }
+        }
+        float t[4][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            t[0][j] = dv[0][j] - dv[2][j];
+            t[1][j] = dv[1][j] + dv[2][j];
+            t[2][j] = dv[2][j] - dv[1][j];
+            t[3][j] = dv[1][j] - dv[3][j];
+            acc[j] += dv[1][j] + dv[2][j];      // d2 is 0 when x = 2i+1 is outside
+        }
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            half8 hi, lo;
+            split8(t[pp], hi, lo, bad);
+            _Float16* o = wb + ((int64_t)pp * Vh + ph) * 32;
+            *reinterpret_cast<half8*>(o) = hi;
+            *reinterpret_cast<half8*>(o + 16) = lo;
+        }
+        if (pb) {
+#pragma unroll
+            for (int k = 1; k <= 2; ++k)
+                if (xo - 1 + k < d.W) {
+                    half8 hi, lo;
+                    split8(dv[k], hi, lo, bad);
+                    _Float16* o = pb + ((int64_t)row * d.W + xo - 1 + k) * 32;
+                    *reinterpret_cast<half8*>(o) = hi;
+                    *reinterpret_cast<half8*>(o + 16) = lo;
+                }
+        }
+    }
+    if (bad) atomicOr(errflag, 1);
+    if (ws) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[tid * 8 + j] = acc[j];
+        __syncthreads();
+        for (int off = SUB >> 1; off > 0; off >>= 1) {
+            if (sub < off) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sh[tid * 8 + j] += sh[((sub + off) * G + g) * 8 + j];
+            }
+            __syncthreads();
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ws[((int64_t)b * nblk + blk) * C + g * 8 + j] = sh[tid * 8 + j];
+        }
+    }
+}
+
+void launch_prep_wino(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, int relu, const float* scale,
+                      SplitView wino, SplitView plain, float* gap, float* ws, int* errflag, hipStream_t st) {
+    int G = C / 8, SUB = 256 / G;
+    int Vh = d.D * d.H * ((d.W + 1) / 2);
+    int nblk = pick_blocks(Vh, SUB * 2, gap ? RED_BLOCKS : 4096);
+    hipLaunchKernelGGL(prep_wino_kernel, dim3(nblk, B), dim3(256), 256 * 8 * sizeof(float), st, x, d, C, mean, rstd, relu, scale,
+                       wino, plain, gap ? ws : nullptr, errflag);
+    if (gap) launch_finalize_sum(ws, B, nblk, C, 1.0f / (float)(d.D * d.H * d.W), gap, st);
+}
+
+// NCDHW f32 [B][C][V] -> wino layout (AF3 encodings for feat_conv, head logits as extra channels)
+__global__ __launch_bounds__(256) void prep_ncdhw_wino_kernel(const float* __restrict__ x, Dims d, int C, SplitView wino,
+                                                              int* __restrict__ errflag) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int Wh = (d.W + 1) >> 1;
+    const int V = d.D * d.H * d.W, Vh = d.D * d.H * Wh;
+    const int ph = blockIdx.x * 256 + threadIdx.x;
+    if (ph >= Vh) return;
+    const int row = ph / Wh, i = ph - row * Wh, xo = 2 * i;
+    bool bad = false;
+    float t[4][16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = ch * 16 + j;
+        float dv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = xo - 1 + k;
+            dv[k] = (c < C && (unsigned)xx < (unsigned)d.W) ? x[((int64_t)b * C + c) * V + (int64_t)row * d.W + xx] : 0.f;
+        }
+        t[0][j] = dv[0] - dv[2]; t[1][j] = dv[1] + dv[2]; t[2][j] = dv[2] - dv[1]; t[3][j] = dv[1] - dv[3];
+    }
+    _Float16* wb = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + ch) * 4 * Vh) * 32;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+        _Float16* o = wb + ((int64_t)pp * Vh + ph) * 32;
+        float y0[8], y1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { y0[j] = t[pp][j]; y1[j] = t[pp][8 + j]; }
+        half8 hi, lo;
+        split8(y0, hi, lo, bad);
+        *reinterpret_cast<half8*>(o) = hi;
+        *reinterpret_cast<half8*>(o + 16) = lo;
+        split8(y1, hi, lo, bad);
+        *reinterpret_cast<half8*>(o + 8) = hi;
+        *reinterpret_cast<half8*>(o + 24) = lo;
+    }
+    if (bad) atomicOr(errflag, 1);
+}
+void launch_prep_ncdhw_wino(const float* x, int B, Dims d, int C, SplitView wino, int* errflag, hipStream_t st) {
+    int Vh = d.D * d.H * ((d.W + 1) / 2);
+    dim3 grid((Vh + 255) / 256, (C + 15) / 16, B);
+    hipLaunchKernelGGL(prep_ncdhw_wino_kernel, grid, dim3(256), 0, st, x, d, C, wino, errflag);
+}
+
 // NCDHW f32 [B][C][V] (the caller's layout, model.py:331) -> split, channels zero-padded to 16.
 __global__ __launch_bounds__(256) void prep_ncdhw_kernel(const float* __restrict__ x, int V, int C, SplitView out,
                                                          float* __restrict__ abs_sum, int* __restrict__ errflag) {
@@ -406,7 +560,8 @@ void launch_feat_gate(const float* x, int B, int V, const float* w0, const float
 __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict__ x, int V, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ gate,
                                                          const float* __restrict__ wf, const float* __restrict__ bf, int ncls,
-                                                         float* __restrict__ logits, SplitView extra, int extra_off) {
+                                                         float* __restrict__ logits, SplitView extra, int extra_off,
+                                                         float* __restrict__ extra_raw, int extra_raw_c) {
     __shared__ float sw[21 * 32];
     __shared__ float sm[32], sr[32], sg[32], sb[21];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -431,6 +586,7 @@ __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 32; ++j) s = fmaf(sw[n * 32 + j], t[j], s);
         logits[((int64_t)b * ncls + n) * V + v] = s;
+        if (extra_raw) extra_raw[((int64_t)b * extra_raw_c + extra_off + n) * V + v] = s;
         if (eo) {
             float xs = s * ASCALE;
             _Float16 h = (_Float16)xs;
@@ -441,9 +597,9 @@ __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict
 }
 void launch_head_final(const float* x, int B, int V, const float* mean, const float* rstd, const float* gate,
                        const float* wf, const float* bf, int ncls, float* logits, SplitView extra, int extra_ch_off,
-                       hipStream_t st) {
+                       float* extra_raw, int extra_raw_c, hipStream_t st) {
     hipLaunchKernelGGL(head_final_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, x, V, mean, rstd, gate, wf, bf,
-                       ncls, logits, extra, extra_ch_off);
+                       ncls, logits, extra, extra_ch_off, extra_raw, extra_raw_c);
 }
 
 // ------------------------------------------------------------------------------------------------
