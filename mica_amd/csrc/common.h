@@ -74,8 +74,12 @@ void launch_gate_mlp(const float* pool, const float* premul, int B, int C, int C
 void launch_fill_float(float* p, int64_t n, float v, hipStream_t st);
 
 // depthwise 3^3 on raw input with fused (x-mean)*rstd, relu, *scale applied on load (zero padding after)
-void launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
-                      const float* scale, const float* w27, const float* bias, float* out, hipStream_t st);
+// C must be a multiple of 4 dividing 1024.  stats_ws (nullable): fused InstanceNorm partials, returns their count P.
+int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
+                     const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, hipStream_t st);
+// merge P partials f32 [B][P][C][3] = (count, mean, M2) into mean / rstd
+void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, float* mean, float* rstd, hipStream_t st);
+int64_t fused_stats_ws_floats(int B, int tile_size);
 // stem: map f32 [B][V] -> split view of 128 channels + gap[b][128] (mean over voxels)
 void launch_stem(const float* map, int B, Dims d, const float* wstem, const float* bstem, SplitView out,
                  float* out_raw, float* gap, float* ws, hipStream_t st);
@@ -93,8 +97,8 @@ void launch_prep_wino(const float* x, int B, Dims d, int C, const float* mean, c
                       const float* scale, SplitView wino, SplitView plain, float* gap, float* ws, int* errflag,
                       hipStream_t st);
 void launch_prep_ncdhw_wino(const float* x, int B, Dims d, int C, SplitView wino, int* errflag, hipStream_t st);
-void launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
-                      float out_scale, float* out, int B, Dims d, int cout, hipStream_t st);
+int launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
+                     float out_scale, float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st);
 void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_seg_c, const int* h_seg_cp, int nseg,
                               const float* cin_scale, int B, float cout_scale, float wscale, _Float16* wpk,
                               hipStream_t st);

@@ -232,7 +232,10 @@ struct SrcList {
     }
 };
 
-void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, hipStream_t st) {
+// Launch a dense conv.  With `norm` (mean/rstd destination given) the InstanceNorm statistics of the output are
+// produced too: fused into the Winograd kernel's epilogue, or by the separate streaming pass otherwise.
+void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, hipStream_t st, float* mean = nullptr,
+              float* rstd = nullptr) {
     if (L.per_tile)
         launch_pack_weights(L.d_w, L.cout, L.cin, L.k, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(),
                             L.d_cin_scale, B, L.cout_scale, L.wscale, L.d_wpk, st);
@@ -242,14 +245,20 @@ void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, 
         e0 = c->ev[c->ev_used++]; e1 = c->ev[c->ev_used++];
         hipEventRecord(e0, st);
     }
+    int P = 0;
     if (L.wino)
-        launch_conv_wino(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout, st);
+        P = launch_conv_wino(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
+                             mean ? c->ws : nullptr, st);
     else
         launch_conv_mfma(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
                          L.k, c->d_err, st);
     if (c->profiling) {
         hipEventRecord(e1, st);
         c->prof_flops += L.flops_per_voxel * (double)c->V * B;
+    }
+    if (mean) {
+        if (L.wino) launch_stats_finalize(c->ws, B, P, L.cout, 1e-5f, mean, rstd, st);
+        else launch_stats(out, B, c->V, L.cout, 1e-5f, mean, rstd, c->ws, st);
     }
 }
 
@@ -299,28 +308,27 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         Enc& E = c->enc[e];
         const int C = E.C, cc = C / 16, ch = C / 32;   // chunks of C and of C/2
         // ResidualDenseBlock (model.py:130-134)
-        run_conv(c, E.conv1, SrcList().add(X, cc, 0, cc), c->R_a, B, st);
-        launch_stats(c->R_a, B, V, C / 2, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        run_conv(c, E.conv1, SrcList().add(X, cc, 0, cc), c->R_a, B, st, c->v_mean, c->v_rstd);
         make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_1, ch, 0, ch), none, nullptr, st);
-        run_conv(c, E.conv2, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch), c->R_a, B, st);
-        launch_stats(c->R_a, B, V, C / 2, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        run_conv(c, E.conv2, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch), c->R_a, B, st, c->v_mean, c->v_rstd);
         make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_2, ch, 0, ch), none, nullptr, st);
-        run_conv(c, E.conv3, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch).add(c->S_2, ch, 0, ch), c->R_b, B, st);
-        launch_stats(c->R_b, B, V, C, 1e-5f, c->v_mean3, c->v_rstd3, c->ws, st);
+        run_conv(c, E.conv3, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch).add(c->S_2, ch, 0, ch), c->R_b, B, st, c->v_mean3,
+                 c->v_rstd3);
         make_operand(c, c->R_b, B, C, c->v_mean3, c->v_rstd3, 1, none, view(c->S_3, cc, 0, cc), c->v_pool, st);
         // SEBlock gate (model.py:254-258); applied downstream: folded into the depthwise load and the fusion weights
         gate(c, E.se, c->v_pool, nullptr, B, nullptr, c->v_gse, nullptr, 0, st);
         // DualAttention (model.py:98-101): local branch
-        launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, c->v_gse, E.dw_w, E.dw_b, c->R_c, st);
-        launch_stats(c->R_c, B, V, C, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        {
+            const int P = launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, c->v_gse, E.dw_w, E.dw_b, c->R_c, c->ws, st);
+            launch_stats_finalize(c->ws, B, P, C, 1e-5f, c->v_mean, c->v_rstd, st);
+        }
         make_operand(c, c->R_c, B, C, c->v_mean, c->v_rstd, 1, none, view(c->S_dw, cc, 0, cc), nullptr, st);
         // global branch: GAP(se(x3)) = g_se * GAP(x3); global_feat = g_ga * g_se * x3 folded into fusion's weights
         gate(c, E.ga, c->v_pool, c->v_gse, B, c->v_gse, nullptr, E.fusion.d_cin_scale + C, 2 * C, st);
         run_conv(c, E.fusion, SrcList().add(c->S_dw, cc, 0, cc).add(c->S_3, cc, 0, cc), c->R_a, B, st);
         make_operand(c, c->R_a, B, C, nullptr, nullptr, 0, view(c->S_f, cc, 0, cc), none, nullptr, st);
         // transition (model.py:141-147); c_e feeds the next encoder's 3^3 convs and the FPN's 1x1 lateral
-        run_conv(c, E.transition, SrcList().add(c->S_f, cc, 0, cc), c->R_a, B, st);
-        launch_stats(c->R_a, B, V, 2 * C, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        run_conv(c, E.transition, SrcList().add(c->S_f, cc, 0, cc), c->R_a, B, st, c->v_mean, c->v_rstd);
         make_operand(c, c->R_a, B, 2 * C, c->v_mean, c->v_rstd, 1, e < 2 ? view(c->S_c[e], 2 * cc, 0, 2 * cc) : none,
                      view(c->S_cp[e], 2 * cc, 0, 2 * cc), nullptr, st);
         X = c->S_c[e];
@@ -342,11 +350,9 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         SrcList src;
         src.add(c->S_fpn, 12, 0, 12);
         if (h > 0) src.add(c->S_extra, 1, 0, 1);
-        run_conv(c, H.conv1, src, c->R_a, B, st);
-        launch_stats(c->R_a, B, V, 64, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        run_conv(c, H.conv1, src, c->R_a, B, st, c->v_mean, c->v_rstd);
         make_operand(c, c->R_a, B, 64, c->v_mean, c->v_rstd, 1, view(c->S_h1, 4, 0, 4), none, nullptr, st);
-        run_conv(c, H.conv2, SrcList().add(c->S_h1, 4, 0, 4), c->R_b, B, st);
-        launch_stats(c->R_b, B, V, 32, 1e-5f, c->v_mean, c->v_rstd, c->ws, st);
+        run_conv(c, H.conv2, SrcList().add(c->S_h1, 4, 0, 4), c->R_b, B, st, c->v_mean, c->v_rstd);
         launch_prep(c->R_b, B, V, 32, c->v_mean, c->v_rstd, 1, nullptr, none, nullptr, c->v_pool, c->ws, c->d_err, st);
         gate(c, H.cal, c->v_pool, nullptr, B, nullptr, c->v_gate, nullptr, 0, st);
         const bool feeds = h < 2;
@@ -482,6 +488,7 @@ int mica_create(int device, int max_batch, int tile_size, mica_ctx** out) {
     int64_t wsn = stats_ws_floats(max_batch, 512);
     int64_t stem_ws = (int64_t)max_batch * 128 * (((tile_size + 31) / 32) * ((tile_size + 7) / 8) * ((tile_size + 1) / 2));
     if (stem_ws > wsn) wsn = stem_ws;
+    if (fused_stats_ws_floats(max_batch, tile_size) > wsn) wsn = fused_stats_ws_floats(max_batch, tile_size);
     if (!r) r = dalloc(c, &c->ws, wsn);
     auto Vv = [&](float** p) { if (!r) r = dalloc(c, p, (int64_t)max_batch * 512); };
     Vv(&c->v_mean); Vv(&c->v_rstd); Vv(&c->v_mean3); Vv(&c->v_rstd3); Vv(&c->v_pool); Vv(&c->v_gse); Vv(&c->v_gate); Vv(&c->v_abs);
@@ -749,7 +756,7 @@ int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int
     if (wino) {
         launch_prep_ncdhw_wino(d_x, batch, Dims{d, h, w}, cin, SplitView{sx, cp / 16, 0, cp / 16}, derr, st);
         launch_pack_weights_wino(dw, cout, cin, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
-        launch_conv_wino(s, pk, 0, db, 1.0f / (ws * ASCALE), raw, batch, Dims{d, h, w}, cout, st);
+        launch_conv_wino(s, pk, 0, db, 1.0f / (ws * ASCALE), raw, batch, Dims{d, h, w}, cout, nullptr, st);
     } else {
         launch_prep_ncdhw(d_x, batch, V, cin, SplitView{sx, cp / 16, 0, cp / 16}, nullptr, derr, st);
         launch_pack_weights(dw, cout, cin, k, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
@@ -787,7 +794,10 @@ int mica_op_instnorm_relu(mica_ctx* c, const float* d_x, int batch, int ch, int 
 int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, int h, int w, const float* h_w, const float* h_b,
                        float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
-    if (!d_x || !d_y || !h_w || !h_b || batch < 1 || ch < 4 || ch % 4 || d < 1 || h < 1 || w < 1) { c->err = "mica_op_depthwise3: bad argument"; return MICA_ERR_ARG; }
+    if (!d_x || !d_y || !h_w || !h_b || batch < 1 || ch < 4 || ch % 4 || 1024 % ch || d < 1 || h < 1 || w < 1) {
+        c->err = "mica_op_depthwise3: bad argument (C must be a multiple of 4 dividing 1024)";
+        return MICA_ERR_ARG;
+    }
     HIPC(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const int V = d * h * w;
@@ -803,7 +813,7 @@ int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, 
     HIPC(c, hipMemcpy(dw, wt.data(), sizeof(float) * 27 * ch, hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(db, h_b, sizeof(float) * ch, hipMemcpyHostToDevice));
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
-    launch_depthwise(a, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, st);
+    launch_depthwise(a, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, nullptr, st);
     launch_nhwc_to_nchw(b, batch, ch, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));

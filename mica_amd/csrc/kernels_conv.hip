@@ -471,7 +471,7 @@ template <int BN, int WN>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
                                                            const float* __restrict__ bias, float out_scale,
                                                            float* __restrict__ out, Dims d, int cout, int total_chunks,
-                                                           int ntx, int nty, int nnb) {
+                                                           int ntx, int nty, int nnb, float* __restrict__ stats_ws) {
     using G = GeoW;
     constexpr int WM = 8 / WN;                     // 4 (positions) when WN = 2 ; WN = 1 => 8 waves = 4 positions x 2 z-halves
     constexpr int FM = (WN == 2) ? 4 : 2;          // z fragments per wave
@@ -607,6 +607,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
             const int n = nb * BN + wn * WNC + j * 32 + col;
             const float bv = bias ? bias[n] : 0.f;
             const int gz = tz * 4 + zz;
+            // InstanceNorm partial statistics of this wave's outputs (shifted sums -> (count, mean, M2))
+            float sn = 0.f, sk = 0.f, s1 = 0.f, s2 = 0.f;
             for (int rr = rhalf; rr < r_n; rr += 2) {
                 const int r = r_lo + rr;
                 const float m0 = src[0 * 1024 + r * 32 + col], m1 = src[1 * 1024 + r * 32 + col];
@@ -615,8 +617,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
                 const int gx = (i0 + pr) * 2, gy = ty * 4 + yy;
                 if (gy < d.H && gz < d.D) {
                     float* o = out + ((int64_t)b * V + (int64_t)(gz * d.H + gy) * d.W + gx) * cout + n;
-                    if (gx < d.W) o[0] = (m0 + m1 + m2) * out_scale + bv;
-                    if (gx + 1 < d.W) o[cout] = (m1 - m2 - m3) * out_scale + bv;
+                    const float ve = (m0 + m1 + m2) * out_scale + bv, vo = (m1 - m2 - m3) * out_scale + bv;
+                    if (gx < d.W) {
+                        o[0] = ve;
+                        if (sn == 0.f) sk = ve;
+                        const float t = ve - sk; s1 += t; s2 = fmaf(t, t, s2); sn += 1.f;
+                    }
+                    if (gx + 1 < d.W) {
+                        o[cout] = vo;
+                        const float t = vo - sk; s1 += t; s2 = fmaf(t, t, s2); sn += 1.f;
+                    }
+                }
+            }
+            if (stats_ws) {
+                float mean = 0.f, m2v = 0.f;
+                if (sn > 0.f) { mean = sk + s1 / sn; m2v = fmaxf(s2 - s1 * s1 / sn, 0.f); }
+                // merge the two half-waves (rows rr even / odd) with Chan's formula
+                const float on = __shfl_xor(sn, 32), om = __shfl_xor(mean, 32), oq = __shfl_xor(m2v, 32);
+                const float tn = sn + on;
+                if (tn > 0.f) {
+                    const float dl = om - mean;
+                    const float mm = (sn > 0.f) ? mean + dl * (on / tn) : om;
+                    const float qq = (sn > 0.f && on > 0.f) ? m2v + oq + dl * dl * (sn * on / tn) : (sn > 0.f ? m2v : oq);
+                    mean = mm; m2v = qq;
+                }
+                if (rhalf == 0) {
+                    constexpr int PW = (WN == 2) ? 4 : 8;
+                    const int slot = tile * PW + ((WN == 2) ? wp : wave);
+                    const int P = (int)(gridDim.x / nnb) * PW;
+                    float* wsp = stats_ws + (((int64_t)b * P + slot) * cout + n) * 3;
+                    wsp[0] = tn; wsp[1] = mean; wsp[2] = m2v;
                 }
             }
         }
@@ -625,8 +655,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
 }
 
 template <int BN, int WN>
-static void launch_conv_wino_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
-                               float* out, int B, Dims d, int cout, hipStream_t st) {
+static int launch_conv_wino_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
+                              float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
     int total = 0;
     for (int i = 0; i < s.n; ++i) total += s.chunks[i];
     int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / BN;
@@ -638,14 +668,17 @@ static void launch_conv_wino_t(const ConvSrcs& s, const _Float16* wpk, int64_t w
     }
     dim3 grid(ntx * nty * ntz * nnb, B);
     hipLaunchKernelGGL((conv_wino_kernel<BN, WN>), grid, dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout,
-                       total, ntx, nty, nnb);
+                       total, ntx, nty, nnb, stats_ws);
+    return ntx * nty * ntz * ((WN == 2) ? 4 : 8);
 }
 
-void launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
-                      float* out, int B, Dims d, int cout, hipStream_t st) {
-    if (cout % 128 == 0) launch_conv_wino_t<128, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-    else if (cout % 64 == 0) launch_conv_wino_t<64, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-    else launch_conv_wino_t<32, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+// Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null):
+// f32 [B][P][cout][3] = (count, mean, M2), to be merged by launch_stats_finalize.
+int launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
+                     float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
+    if (cout % 128 == 0) return launch_conv_wino_t<128, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
+    if (cout % 64 == 0) return launch_conv_wino_t<64, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
+    return launch_conv_wino_t<32, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
 }
 
 // weights for conv_wino: [B][chunk][tap 9 = (dz,dy)][p 4][q 4][Cout][8] halves, u = G g along kw
@@ -813,50 +846,120 @@ void launch_pack_weights(const float* w, int cout, int cin, int ksize, const int
 //   y = scale[c] * relu((x - mean[c]) * rstd[c]);  out = sum_tap w[tap][c] * y(shifted, zero padded) + bias
 // HBM-bound (8 B/voxel/channel algorithmic); the 27 shifted reads are served by L1/L2.
 // ------------------------------------------------------------------------------------------------
+constexpr int DW_RUN = 8;   // consecutive x outputs per thread
 __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict__ x, Dims d, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ scale, const float* __restrict__ w27,
-                                                        const float* __restrict__ bias, float* __restrict__ out) {
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        float* __restrict__ stats_ws) {
+    extern __shared__ float sh[];   // [3][256][4] statistics merge
     const int b = blockIdx.y;
     const int V = d.D * d.H * d.W;
-    const int c4n = C >> 2;
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)V * c4n) return;
-    const int c = (int)(e % c4n) * 4;
-    const int v = (int)(e / c4n);
-    const int xw = v % d.W, yh = (v / d.W) % d.H, zd = v / (d.W * d.H);
+    const int CG = C >> 2, RPB = 256 / CG;               // channel groups, x-runs per block
+    const int tid = threadIdx.x, cg = tid % CG, rl = tid / CG;
+    const int nruns_x = (d.W + DW_RUN - 1) / DW_RUN;
+    const int nruns = d.D * d.H * nruns_x;
+    const int run = blockIdx.x * RPB + rl;
+    const int c = cg * 4;
     float4 m = make_float4(0, 0, 0, 0), r = make_float4(1, 1, 1, 1), sc = make_float4(1, 1, 1, 1);
     if (mean) { m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c); r = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c); }
     if (scale) sc = *reinterpret_cast<const float4*>(scale + (int64_t)b * C + c);
-    float4 acc = *reinterpret_cast<const float4*>(bias + c);
-    const float* xb = x + (int64_t)b * V * C;
+    float sn = 0.f;
+    float4 sk = make_float4(0, 0, 0, 0), s1 = sk, s2 = sk;
+    if (run < nruns) {
+        const int xr = run % nruns_x, row = run / nruns_x;
+        const int yh = row % d.H, zd = row / d.H, x0 = xr * DW_RUN;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+        float4 acc[DW_RUN];
 #pragma unroll
-    for (int dz = -1; dz <= 1; ++dz)
+        for (int i = 0; i < DW_RUN; ++i) acc[i] = bv;
+        const float* xb = x + (int64_t)b * V * C + c;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                int zz = zd + dz, yy = yh + dy, xx = xw + dx;
-                if ((unsigned)zz < (unsigned)d.D && (unsigned)yy < (unsigned)d.H && (unsigned)xx < (unsigned)d.W) {
-                    float4 t = *reinterpret_cast<const float4*>(xb + ((int64_t)(zz * d.H + yy) * d.W + xx) * C + c);
-                    if (mean) {
-                        t.x = fmaxf((t.x - m.x) * r.x, 0.f) * sc.x; t.y = fmaxf((t.y - m.y) * r.y, 0.f) * sc.y;
-                        t.z = fmaxf((t.z - m.z) * r.z, 0.f) * sc.z; t.w = fmaxf((t.w - m.w) * r.w, 0.f) * sc.w;
-                    } else { t.x *= sc.x; t.y *= sc.y; t.z *= sc.z; t.w *= sc.w; }
-                    const int tap = ((dz + 1) * 3 + (dy + 1)) * 3 + (dx + 1);
-                    float4 wv = *reinterpret_cast<const float4*>(w27 + tap * C + c);
-                    acc.x = fmaf(wv.x, t.x, acc.x); acc.y = fmaf(wv.y, t.y, acc.y);
-                    acc.z = fmaf(wv.z, t.z, acc.z); acc.w = fmaf(wv.w, t.w, acc.w);
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int zz = zd + dz, yy = yh + dy;
+                if ((unsigned)zz < (unsigned)d.D && (unsigned)yy < (unsigned)d.H) {
+                    const float* rowp = xb + ((int64_t)(zz * d.H + yy) * d.W) * C;
+                    float4 win[DW_RUN + 2];
+#pragma unroll
+                    for (int i = 0; i < DW_RUN + 2; ++i) {
+                        const int xx = x0 - 1 + i;
+                        const bool ok = (unsigned)xx < (unsigned)d.W;
+                        float4 t = *reinterpret_cast<const float4*>(rowp + (int64_t)(ok ? xx : x0) * C);
+                        if (mean) {
+                            t.x = fmaxf((t.x - m.x) * r.x, 0.f) * sc.x; t.y = fmaxf((t.y - m.y) * r.y, 0.f) * sc.y;
+                            t.z = fmaxf((t.z - m.z) * r.z, 0.f) * sc.z; t.w = fmaxf((t.w - m.w) * r.w, 0.f) * sc.w;
+                        } else { t.x *= sc.x; t.y *= sc.y; t.z *= sc.z; t.w *= sc.w; }
+                        win[i] = ok ? t : make_float4(0, 0, 0, 0);
+                    }
+                    const int tap0 = ((dz + 1) * 3 + (dy + 1)) * 3;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float4 wv = *reinterpret_cast<const float4*>(w27 + (tap0 + dx) * C + c);
+#pragma unroll
+                        for (int i = 0; i < DW_RUN; ++i) {
+                            acc[i].x = fmaf(wv.x, win[i + dx].x, acc[i].x); acc[i].y = fmaf(wv.y, win[i + dx].y, acc[i].y);
+                            acc[i].z = fmaf(wv.z, win[i + dx].z, acc[i].z); acc[i].w = fmaf(wv.w, win[i + dx].w, acc[i].w);
+                        }
+                    }
                 }
             }
-    *reinterpret_cast<float4*>(out + ((int64_t)b * V + v) * C + c) = acc;
+        float* ob = out + ((int64_t)b * V + (int64_t)(zd * d.H + yh) * d.W) * C + c;
+#pragma unroll
+        for (int i = 0; i < DW_RUN; ++i)
+            if (x0 + i < d.W) {
+                *reinterpret_cast<float4*>(ob + (int64_t)(x0 + i) * C) = acc[i];
+                if (sn == 0.f) sk = acc[i];
+                const float4 t = make_float4(acc[i].x - sk.x, acc[i].y - sk.y, acc[i].z - sk.z, acc[i].w - sk.w);
+                s1.x += t.x; s1.y += t.y; s1.z += t.z; s1.w += t.w;
+                s2.x = fmaf(t.x, t.x, s2.x); s2.y = fmaf(t.y, t.y, s2.y); s2.z = fmaf(t.z, t.z, s2.z); s2.w = fmaf(t.w, t.w, s2.w);
+                sn += 1.f;
+            }
+    }
+    if (!stats_ws) return;
+    // block merge of (count, mean, M2) over the x-runs, then one partial per block and channel
+    float* shn = sh; float* shm = sh + 1024; float* shq = sh + 2048;
+    const float kk[4] = {sk.x, sk.y, sk.z, sk.w}, a1[4] = {s1.x, s1.y, s1.z, s1.w}, a2[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float mean_ = 0.f, m2 = 0.f;
+        if (sn > 0.f) { mean_ = kk[j] + a1[j] / sn; m2 = fmaxf(a2[j] - a1[j] * a1[j] / sn, 0.f); }
+        shn[tid * 4 + j] = sn; shm[tid * 4 + j] = mean_; shq[tid * 4 + j] = m2;
+    }
+    __syncthreads();
+    for (int off = RPB >> 1; off > 0; off >>= 1) {
+        if (rl < off) {
+            const int o = (rl + off) * CG + cg;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float na = shn[tid * 4 + j], ma = shm[tid * 4 + j], qa = shq[tid * 4 + j];
+                const float nb2 = shn[o * 4 + j], mb = shm[o * 4 + j], qb = shq[o * 4 + j];
+                if (nb2 > 0.f) {
+                    if (na == 0.f) { na = nb2; ma = mb; qa = qb; }
+                    else { const float nn = na + nb2, dl = mb - ma; ma += dl * (nb2 / nn); qa += qb + dl * dl * (na * nb2 / nn); na = nn; }
+                }
+                shn[tid * 4 + j] = na; shm[tid * 4 + j] = ma; shq[tid * 4 + j] = qa;
+            }
+        }
+        __syncthreads();
+    }
+    if (rl == 0) {
+        float* wsp = stats_ws + (((int64_t)b * gridDim.x + blockIdx.x) * C + c) * 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wsp[j * 3] = shn[tid * 4 + j]; wsp[j * 3 + 1] = shm[tid * 4 + j]; wsp[j * 3 + 2] = shq[tid * 4 + j]; }
+    }
 }
 
-void launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
-                      const float* scale, const float* w27, const float* bias, float* out, hipStream_t st) {
-    int64_t n = (int64_t)d.D * d.H * d.W * (C / 4);
-    dim3 grid((unsigned)((n + 255) / 256), B);
-    hipLaunchKernelGGL(depthwise_kernel, grid, dim3(256), 0, st, x, d, C, mean, rstd, scale, w27, bias, out);
+// Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null).
+int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
+                     const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, hipStream_t st) {
+    const int CG = C / 4, RPB = 256 / CG;
+    const int nruns = d.D * d.H * ((d.W + DW_RUN - 1) / DW_RUN);
+    dim3 grid((unsigned)((nruns + RPB - 1) / RPB), B);
+    hipLaunchKernelGGL(depthwise_kernel, grid, dim3(256), 3 * 1024 * sizeof(float), st, x, d, C, mean, rstd, scale, w27, bias, out,
+                       stats_ws);
+    return (int)grid.x;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -123,6 +123,18 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
 }
 
 int64_t stats_ws_floats(int B, int C) { return (int64_t)B * RED_BLOCKS * C * 3; }
+void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, float* mean, float* rstd, hipStream_t st) {
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd);
+}
+// fused statistics: conv_wino writes 4 partials per 16x4x4 output tile (8 for Cout = 32), depthwise one per block
+int64_t fused_stats_ws_floats(int B, int S) {
+    int64_t tiles = (int64_t)((S + 15) / 16) * ((S + 3) / 4) * ((S + 3) / 4);
+    int64_t a = tiles * 4 * 512 * 3, bb = tiles * 8 * 32 * 3;
+    int64_t dwp = (int64_t)S * S * ((S + 7) / 8) * 64 * 3;       // depthwise: runs/RPB blocks x C, worst at C = 256
+    int64_t m = a > bb ? a : bb;
+    if (dwp > m) m = dwp;
+    return m * B;
+}
 
 void launch_stats(const float* x, int B, int V, int C, float eps, float* mean, float* rstd, float* ws, hipStream_t st) {
     int G = C / 8, SUB = 256 / G;
