@@ -122,21 +122,35 @@ def main():
     tiles = args.steps * B * world
     value = tiles / dt
 
-    # dense-conv roofline: HIP events around every conv_mfma launch of one extra (untimed) batch
-    roof = None
+    # rooflines: HIP events (on the launch stream, inside the library) around every dense-conv and every depthwise
+    # conv3d launch of one extra, untimed batch.  PMC traffic comes from the committed rocprofv3 passes (profiles/).
+    roof = hbm = None
     if rank == 0:
         eng.set_profiling(True)
         vp.run_batch(vol, af, 0, B)
         torch.cuda.synchronize()
-        ms, launches, flops = eng.conv_profile()
+        ms, launches, flops = eng.profile(0)
+        dms, dl, dbytes = eng.profile(1)
         eng.set_profiling(False)
+        traffic = {}
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tp):
+            traffic = json.load(open(tp)).get("kernels", {})
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_mfma_kernel (dense 3x3x3 / 1x1x1 conv, split-f16 x3 MFMA)",
-                "achieved": ach, "peak": PEAK_SPLIT_TF, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TF, "traffic": None,
+        roof = {"bound": "mfma", "kernel": "conv_wino_kernel + conv2_kernel (dense 3x3x3 via Winograd F(2,3)-x, 1x1x1; split-f16 x3 MFMA)",
+                "achieved": ach, "peak": PEAK_SPLIT_TF, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TF,
+                "traffic": traffic.get("conv_wino_kernel", {}).get("hbm_bytes"),
                 "launches_per_batch": launches, "avg_launch_ms": ms / max(launches, 1),
                 "algorithmic_gflop_per_launch_avg": flops / max(launches, 1) / 1e9,
-                "note": "achieved = algorithmic conv FLOPs (2*27*Cin*Cout*V, unpadded) / HIP-event time of the conv "
-                        "launches; peak = f16 dense MFMA 2500 TF / 3 MFMAs per f32-grade product"}
+                "note": "achieved = algorithmic direct-conv FLOPs (2*k^3*Cin*Cout*V, unpadded) / HIP-event time of the conv launches; "
+                        "peak = f16 dense MFMA 2500 TF / 3 MFMAs per f32-grade product; Winograd executes 1.5x fewer MFMAs than the "
+                        "algorithmic count; traffic = PMC HBM bytes per conv_wino launch at batch 4 (profiles/r01_pmc_traffic.json)"}
+        dach = dbytes / (dms * 1e-3) / 1e9
+        hbm = {"bound": "hbm", "kernel": "depthwise_kernel (Conv3d groups=C, 3x3x3, IN+ReLU+SE gate fused on load, IN stats fused)",
+               "achieved": dach, "peak": 8000.0, "unit": "GB/s", "frac": dach / 8000.0,
+               "traffic": traffic.get("depthwise_kernel", {}).get("hbm_bytes"), "launches_per_batch": dl,
+               "avg_launch_ms": dms / max(dl, 1),
+               "note": "BASELINE metric's 'HBM GB/s on conv3d': algorithmic 8 B per voxel and channel / HIP-event time"}
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         S = args.grid + 2 * args.pad
@@ -152,7 +166,7 @@ def main():
                                    f"{T} tiles per map, {B} tiles per step per GPU, gather+forward+softmax+stitch"
                                    + ("" if world == 1 else ", RCCL all-gather of cropped records to every rank, rank 0 stitches"),
                        "tiles_per_step": B * world, "af_path": not args.no_af, "flops_per_tile": FLOPS_PER_TILE_AF},
-            "roofline": roof, "cpu_baseline": cpu}))
+            "roofline": roof, "hbm_conv3d": hbm, "cpu_baseline": cpu}))
     if world > 1:
         dist.destroy_process_group()
 

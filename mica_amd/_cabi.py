@@ -41,6 +41,7 @@ SIGNATURES = {
     "mica_op_stem": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "mica_set_profiling": (_I, [_P, _I]),
     "mica_get_conv_profile": (_I, [_P, _DP, _LP, _DP]),
+    "mica_get_profile": (_I, [_P, _I, _DP, _LP, _DP]),
 }
 
 _lib = None

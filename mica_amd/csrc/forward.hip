@@ -92,13 +92,14 @@ struct mica_ctx {
     float* h_abs = nullptr;       // pinned
     int* h_err = nullptr;         // pinned
 
-    // profiling of the dense-conv launches
+    // profiling: HIP events around the launches of kind 0 = dense conv (work = FLOPs), 1 = depthwise conv3d (work = bytes)
     bool profiling = false;
     std::vector<hipEvent_t> ev;
+    std::vector<int> ev_kind;
     size_t ev_used = 0;
-    double prof_flops = 0;
-    double last_ms = 0, last_flops = 0;
-    int64_t last_launches = 0;
+    double prof_work[2] = {0, 0};
+    double last_ms[2] = {0, 0}, last_work[2] = {0, 0};
+    int64_t last_launches[2] = {0, 0};
 };
 
 namespace {
@@ -232,6 +233,19 @@ struct SrcList {
     }
 };
 
+void prof_begin(mica_ctx* c, int kind, hipStream_t st) {
+    if (!c->profiling) return;
+    while (c->ev.size() < c->ev_used + 2) { hipEvent_t e; hipEventCreate(&e); c->ev.push_back(e); c->ev_kind.push_back(0); }
+    c->ev_kind[c->ev_used] = kind;
+    hipEventRecord(c->ev[c->ev_used], st);
+}
+void prof_end(mica_ctx* c, int kind, double work, hipStream_t st) {
+    if (!c->profiling) return;
+    hipEventRecord(c->ev[c->ev_used + 1], st);
+    c->ev_used += 2;
+    c->prof_work[kind] += work;
+}
+
 // Launch a dense conv.  With `norm` (mean/rstd destination given) the InstanceNorm statistics of the output are
 // produced too: fused into the Winograd kernel's epilogue, or by the separate streaming pass otherwise.
 void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, hipStream_t st, float* mean = nullptr,
@@ -239,12 +253,7 @@ void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, 
     if (L.per_tile)
         launch_pack_weights(L.d_w, L.cout, L.cin, L.k, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(),
                             L.d_cin_scale, B, L.cout_scale, L.wscale, L.d_wpk, st);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profiling) {
-        while (c->ev.size() < c->ev_used + 2) { hipEvent_t e; hipEventCreate(&e); c->ev.push_back(e); }
-        e0 = c->ev[c->ev_used++]; e1 = c->ev[c->ev_used++];
-        hipEventRecord(e0, st);
-    }
+    prof_begin(c, 0, st);
     int P = 0;
     if (L.wino)
         P = launch_conv_wino(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
@@ -252,10 +261,7 @@ void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, 
     else
         launch_conv_mfma(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
                          L.k, c->d_err, st);
-    if (c->profiling) {
-        hipEventRecord(e1, st);
-        c->prof_flops += L.flops_per_voxel * (double)c->V * B;
-    }
+    prof_end(c, 0, L.flops_per_voxel * (double)c->V * B, st);
     if (mean) {
         if (L.wino) launch_stats_finalize(c->ws, B, P, L.cout, 1e-5f, mean, rstd, st);
         else launch_stats(out, B, c->V, L.cout, 1e-5f, mean, rstd, c->ws, st);
@@ -319,7 +325,9 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         gate(c, E.se, c->v_pool, nullptr, B, nullptr, c->v_gse, nullptr, 0, st);
         // DualAttention (model.py:98-101): local branch
         {
+            prof_begin(c, 1, st);
             const int P = launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, c->v_gse, E.dw_w, E.dw_b, c->R_c, c->ws, st);
+            prof_end(c, 1, 8.0 * (double)C * V * B, st);     // algorithmic bytes: read + write 4 B per voxel and channel
             launch_stats_finalize(c->ws, B, P, C, 1e-5f, c->v_mean, c->v_rstd, st);
         }
         make_operand(c, c->R_c, B, C, c->v_mean, c->v_rstd, 1, none, view(c->S_dw, cc, 0, cc), nullptr, st);
@@ -373,7 +381,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     HIPC(c, hipSetDevice(c->device));
     const int V = c->V;
     c->ev_used = 0;
-    c->prof_flops = 0;
+    c->prof_work[0] = c->prof_work[1] = 0;
     HIPC(c, hipMemsetAsync(c->d_err, 0, sizeof(int), st));
     std::vector<char> use(B, 0);
     if (d_af && af_mode != MICA_AF_NONE) {
@@ -401,15 +409,15 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     HIPC(c, hipGetLastError());
     if (c->profiling) {
         HIPC(c, hipStreamSynchronize(st));
-        double ms = 0;
+        double ms[2] = {0, 0};
+        int64_t n[2] = {0, 0};
         for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
             float t = 0;
             hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]);
-            ms += t;
+            ms[c->ev_kind[i]] += t;
+            n[c->ev_kind[i]]++;
         }
-        c->last_ms = ms;
-        c->last_launches = (int64_t)(c->ev_used / 2);
-        c->last_flops = c->prof_flops;
+        for (int k = 0; k < 2; ++k) { c->last_ms[k] = ms[k]; c->last_launches[k] = n[k]; c->last_work[k] = c->prof_work[k]; }
     }
     return MICA_OK;
 }
@@ -794,8 +802,8 @@ int mica_op_instnorm_relu(mica_ctx* c, const float* d_x, int batch, int ch, int 
 int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, int h, int w, const float* h_w, const float* h_b,
                        float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
-    if (!d_x || !d_y || !h_w || !h_b || batch < 1 || ch < 4 || ch % 4 || 1024 % ch || d < 1 || h < 1 || w < 1) {
-        c->err = "mica_op_depthwise3: bad argument (C must be a multiple of 4 dividing 1024)";
+    if (!d_x || !d_y || !h_w || !h_b || batch < 1 || ch < 32 || ch % 32 || d < 1 || h < 1 || w < 1) {
+        c->err = "mica_op_depthwise3: bad argument (C must be a multiple of 32)";
         return MICA_ERR_ARG;
     }
     HIPC(c, hipSetDevice(c->device));
@@ -843,12 +851,16 @@ int mica_set_profiling(mica_ctx* c, int enable) {
     return MICA_OK;
 }
 
-int mica_get_conv_profile(mica_ctx* c, double* h_ms_total, int64_t* h_launches, double* h_flops) {
-    if (!c || !h_ms_total || !h_launches || !h_flops) return MICA_ERR_ARG;
-    *h_ms_total = c->last_ms;
-    *h_launches = c->last_launches;
-    *h_flops = c->last_flops;
+int mica_get_profile(mica_ctx* c, int kind, double* h_ms_total, int64_t* h_launches, double* h_work) {
+    if (!c || kind < 0 || kind > 1 || !h_ms_total || !h_launches || !h_work) return MICA_ERR_ARG;
+    *h_ms_total = c->last_ms[kind];
+    *h_launches = c->last_launches[kind];
+    *h_work = c->last_work[kind];
     return MICA_OK;
+}
+
+int mica_get_conv_profile(mica_ctx* c, double* h_ms_total, int64_t* h_launches, double* h_flops) {
+    return mica_get_profile(c, 0, h_ms_total, h_launches, h_flops);
 }
 
 }  // extern "C"

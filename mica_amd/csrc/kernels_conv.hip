@@ -855,12 +855,20 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict_
     extern __shared__ float sh[];   // [3][256][4] statistics merge
     const int b = blockIdx.y;
     const int V = d.D * d.H * d.W;
-    const int CG = C >> 2, RPB = 256 / CG;               // channel groups, x-runs per block
-    const int tid = threadIdx.x, cg = tid % CG, rl = tid / CG;
+    // A block = 32 channels x 32 x-runs.  Blocks are ordered channel-block outermost and each XCD gets a
+    // contiguous range of them, so the three z planes a run reads (0.5 MB per plane at 32 channels) stay in that
+    // XCD's L2 instead of being re-fetched from HBM (7.5x read amplification measured with all channels per block).
+    constexpr int CG = 8, RPB = 32;
+    const int tid = threadIdx.x, cg = tid & 7, rl = tid >> 3;
     const int nruns_x = (d.W + DW_RUN - 1) / DW_RUN;
     const int nruns = d.D * d.H * nruns_x;
-    const int run = blockIdx.x * RPB + rl;
-    const int c = cg * 4;
+    const int nrb = (nruns + RPB - 1) / RPB;
+    int id = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
+    const int cblk = id / nrb, rb = id - cblk * nrb;
+    const int run = rb * RPB + rl;
+    const int c = cblk * 32 + cg * 4;
     float4 m = make_float4(0, 0, 0, 0), r = make_float4(1, 1, 1, 1), sc = make_float4(1, 1, 1, 1);
     if (mean) { m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c); r = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c); }
     if (scale) sc = *reinterpret_cast<const float4*>(scale + (int64_t)b * C + c);
@@ -945,7 +953,7 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict_
         __syncthreads();
     }
     if (rl == 0) {
-        float* wsp = stats_ws + (((int64_t)b * gridDim.x + blockIdx.x) * C + c) * 3;
+        float* wsp = stats_ws + (((int64_t)b * nrb + rb) * C + c) * 3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { wsp[j * 3] = shn[tid * 4 + j]; wsp[j * 3 + 1] = shm[tid * 4 + j]; wsp[j * 3 + 2] = shq[tid * 4 + j]; }
     }
@@ -954,13 +962,14 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict_
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null).
 int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, hipStream_t st) {
-    const int CG = C / 4, RPB = 256 / CG;
     const int nruns = d.D * d.H * ((d.W + DW_RUN - 1) / DW_RUN);
-    dim3 grid((unsigned)((nruns + RPB - 1) / RPB), B);
+    const int nrb = (nruns + 31) / 32;
+    dim3 grid((unsigned)(nrb * (C / 32)), B);
     hipLaunchKernelGGL(depthwise_kernel, grid, dim3(256), 3 * 1024 * sizeof(float), st, x, d, C, mean, rstd, scale, w27, bias, out,
                        stats_ws);
-    return (int)grid.x;
+    return nrb;
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // Multi-scale stem (model.py:9-14,49-51): four Conv3d(1,32,k) with k = 3,5,7,9 on the density tile.

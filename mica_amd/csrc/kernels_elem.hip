@@ -130,7 +130,7 @@ void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, floa
 int64_t fused_stats_ws_floats(int B, int S) {
     int64_t tiles = (int64_t)((S + 15) / 16) * ((S + 3) / 4) * ((S + 3) / 4);
     int64_t a = tiles * 4 * 512 * 3, bb = tiles * 8 * 32 * 3;
-    int64_t dwp = (int64_t)S * S * ((S + 7) / 8) * 64 * 3;       // depthwise: runs/RPB blocks x C, worst at C = 256
+    int64_t dwp = ((int64_t)S * S * ((S + 7) / 8) + 31) / 32 * 256 * 3;   // depthwise: one partial per 32 x-runs, C <= 256
     int64_t m = a > bb ? a : bb;
     if (dwp > m) m = dwp;
     return m * B;

@@ -203,6 +203,10 @@ class Engine:
         self._check(self.lib.mica_set_profiling(self._h, int(on)), "mica_set_profiling")
 
     def conv_profile(self):
-        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
-        self._check(self.lib.mica_get_conv_profile(self._h, C.byref(ms), C.byref(n), C.byref(fl)), "mica_get_conv_profile")
-        return ms.value, n.value, fl.value
+        return self.profile(0)
+
+    def profile(self, kind: int):
+        """(ms, launches, work) of the last profiled forward: kind 0 dense convs (FLOPs), 1 depthwise conv3d (bytes)."""
+        ms, n, wk = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self.lib.mica_get_profile(self._h, kind, C.byref(ms), C.byref(n), C.byref(wk)), "mica_get_profile")
+        return ms.value, n.value, wk.value

@@ -10,12 +10,15 @@ if len(sys.argv) >= 4:
     shapes = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))]
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+zero = os.environ.get('ZERO', '0') == '1'
 e = Engine(0, max_batch=1, tile_size=16)
 for cin, cout, k in shapes:
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.rand((1, cin, S, S, S), generator=g, device="cuda") * 2 - 0.5
     w = ((np.random.default_rng(2).random((cout, cin, k, k, k), dtype=np.float32) * 2 - 1) * (3.0 / (cin * k ** 3)) ** 0.5).astype(np.float32)
     b = np.zeros(cout, np.float32)
+    if zero:
+        x = torch.zeros_like(x); w = np.zeros_like(w)
     e.set_profiling(False)
     for _ in range(reps):
         y = e.op_conv3d(x, w, b, k)
