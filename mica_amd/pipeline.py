@@ -60,6 +60,56 @@ class VolumePredictor:
         return {"backbone_probability": out[0], "carbon_alpha_probability": out[1],
                 "amino_acid_prediction": out[2], "amino_acid_probability": out[3:]}
 
+    def predict_maps_streamed(self, maps, afs=None):
+        """Several independent maps back to back (BASELINE.json configs[4]): host arrays are staged through two
+        pinned buffers and uploaded with hipMemcpyAsync on a copy stream while the previous map computes
+        (double-buffered H2D); results come back as dicts of host arrays.  `maps`: list of float32 [N0,N1,N2]
+        numpy arrays, `afs`: optional list of float32 [24,N0,N1,N2] (or None entries)."""
+        import numpy as np
+        e = self.e
+        dev = e.device
+        copy_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        afs = afs or [None] * len(maps)
+        slots = [None, None]          # (pinned map, pinned af, device map, device af, ready event)
+
+        def stage(i):
+            m = np.ascontiguousarray(maps[i], dtype=np.float32)
+            a = None if afs[i] is None else np.ascontiguousarray(afs[i], dtype=np.float32)
+            k = i & 1
+            prev = slots[k]
+            pm = prev[0] if prev is not None and prev[0].shape == m.shape else torch.empty(m.shape, dtype=torch.float32, pin_memory=True)
+            pm.copy_(torch.from_numpy(m))
+            pa = None
+            if a is not None:
+                pa = prev[1] if prev is not None and prev[1] is not None and prev[1].shape == a.shape else \
+                    torch.empty(a.shape, dtype=torch.float32, pin_memory=True)
+                pa.copy_(torch.from_numpy(a))
+            with torch.cuda.stream(copy_stream):
+                dm = pm.to(dev, non_blocking=True)
+                da = None if pa is None else pa.to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            slots[k] = (pm, pa, dm, da, ev)
+
+        results = []
+        if maps:
+            stage(0)
+        for i in range(len(maps)):
+            pm, pa, dm, da, ev = slots[i & 1]
+            if i + 1 < len(maps):
+                # the other slot's previous tensors were consumed by map i-1, whose kernels are already enqueued on
+                # `main`; make the copy stream wait for them before the buffers are overwritten
+                copy_stream.wait_stream(main)
+                stage(i + 1)
+            main.wait_event(ev)
+            dm.record_stream(main)
+            if da is not None:
+                da.record_stream(main)
+            out = self.predict_volume(dm, da)
+            results.append({k: v.cpu().numpy() for k, v in out.items()})
+        return results
+
     def predict_volume_sharded(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None, group=None):
         """Multi-GPU form: every rank holds the (normalised) volume, runs its share of the tile batches and
         the cropped records are all-gathered (RCCL); rank 0 returns the dict, the other ranks return None."""

@@ -203,3 +203,29 @@ def test_mica_module_mirror(weights, golden_dir):
     bb, ca, aa = m(x, af)
     assert bb.shape == (1, 4, 8, 8, 8) and aa.shape == (1, 21, 8, 8, 8)
     assert _scaled(aa.cpu().numpy(), g["aa"]) < 1e-4
+
+
+def test_streamed_maps_double_buffered_h2d(eng):
+    """BASELINE configs[4] in miniature: independent maps streamed back to back equal one-at-a-time results."""
+    from mica_amd.pipeline import VolumePredictor
+    vp = VolumePredictor(eng, 48, 8, batch=2)
+    maps = [synth_density((50, 40, 30), s) for s in (71, 72, 73)]
+    afs = [None, synth_af((50, 40, 30), 72, 0.01), None]
+    got = vp.predict_maps_streamed(maps, afs)
+    assert len(got) == 3
+    for m, a, g in zip(maps, afs, got):
+        ref = vp.predict_volume(torch.from_numpy(m).cuda(), None if a is None else torch.from_numpy(a).cuda())
+        for k in ref:
+            assert g[k].dtype == np.float32 and np.array_equal(g[k], ref[k].cpu().numpy()), k
+
+
+def test_sharded_single_rank_equals_plain(eng):
+    """predict_volume_sharded with one rank (no process group) is the plain pipeline; the 2-rank rendezvous
+    itself is covered by the gloo tests."""
+    from mica_amd.pipeline import VolumePredictor
+    vp = VolumePredictor(eng, 48, 8, batch=2)
+    vol = torch.from_numpy(synth_density((60, 50, 40), 81)).cuda()
+    a = vp.predict_volume(vol)
+    b = vp.predict_volume_sharded(vol)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
