@@ -78,29 +78,27 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
     }
 }
 
-// one workgroup per (tile, 4 channels): 64 lanes merge the block partials of a channel (f64 Chan merges,
-// fixed lane->partial assignment and fixed tree => deterministic)
+// one workgroup per (tile, channel): 256 threads merge the block partials (f64 Chan merges, fixed thread->partial
+// assignment and fixed tree => deterministic)
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ ws, int nblk, int C, float eps,
                                                              float* __restrict__ mean, float* __restrict__ rstd) {
     __shared__ double sn[256], sm[256], sq[256];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const int c = blockIdx.x * 4 + (tid >> 6);
+    const int b = blockIdx.y, tid = threadIdx.x, c = blockIdx.x;
     double n = 0, m = 0, q = 0;
-    if (c < C)
-        for (int k = lane; k < nblk; k += 64) {
-            const float* w = ws + (((int64_t)b * nblk + k) * C + c) * 3;
-            double nb = w[0], mb = w[1], qb = w[2];
-            if (nb > 0) {
-                double nn = n + nb, dl = mb - m;
-                m += dl * (nb / nn);
-                q += qb + dl * dl * (n * nb / nn);
-                n = nn;
-            }
+    for (int k = tid; k < nblk; k += 256) {
+        const float* w = ws + (((int64_t)b * nblk + k) * C + c) * 3;
+        double nb = w[0], mb = w[1], qb = w[2];
+        if (nb > 0) {
+            double nn = n + nb, dl = mb - m;
+            m += dl * (nb / nn);
+            q += qb + dl * dl * (n * nb / nn);
+            n = nn;
         }
+    }
     sn[tid] = n; sm[tid] = m; sq[tid] = q;
     __syncthreads();
-    for (int off = 32; off > 0; off >>= 1) {
-        if (lane < off) {
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
             double nb = sn[tid + off], mb = sm[tid + off], qb = sq[tid + off];
             double na = sn[tid], ma = sm[tid], qa = sq[tid];
             if (nb > 0) {
@@ -116,15 +114,15 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
         }
         __syncthreads();
     }
-    if (lane == 0 && c < C) {
-        mean[(int64_t)b * C + c] = (float)sm[tid];
-        rstd[(int64_t)b * C + c] = (float)(1.0 / sqrt(sq[tid] / sn[tid] + (double)eps));
+    if (tid == 0) {
+        mean[(int64_t)b * C + c] = (float)sm[0];
+        rstd[(int64_t)b * C + c] = (float)(1.0 / sqrt(sq[0] / sn[0] + (double)eps));
     }
 }
 
 int64_t stats_ws_floats(int B, int C) { return (int64_t)B * RED_BLOCKS * C * 3; }
 void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, float* mean, float* rstd, hipStream_t st) {
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(C, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd);
 }
 // fused statistics: conv_wino writes 4 partials per 16x4x4 output tile (8 for Cout = 32), depthwise one per block
 int64_t fused_stats_ws_floats(int B, int S) {
@@ -140,7 +138,7 @@ void launch_stats(const float* x, int B, int V, int C, float eps, float* mean, f
     int G = C / 8, SUB = 256 / G;
     int nblk = pick_blocks(V, SUB * 8, RED_BLOCKS);
     hipLaunchKernelGGL(stats_kernel, dim3(nblk, B), dim3(256), 3 * 256 * 8 * sizeof(float), st, x, V, C, ws);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(C, B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd);
 }
 
 __global__ __launch_bounds__(256) void finalize_sum_kernel(const float* __restrict__ ws, int nblocks, int C, float inv,
@@ -184,9 +182,12 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, 
                                                    float* __restrict__ out_raw, float* __restrict__ ws,
                                                    int* __restrict__ errflag) {
     extern __shared__ float sh[];   // [256][8] for the gap reduction
+    // A block covers a slab of at most 64 channels (blockIdx.z): with all C channels per block a wave's stores
+    // scatter over C/16 chunk planes in 32-B pieces (2.6 TB/s at C = 512 vs 5.3 TB/s at C = 64 measured).
     const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
-    const int G = C >> 3, SUB = 256 / G;
-    const int tid = threadIdx.x, g = tid % G, sub = tid / G;
+    const int Cs = C < 64 ? C : 64;
+    const int G = Cs >> 3, SUB = 256 / G;
+    const int tid = threadIdx.x, g = blockIdx.z * (Cs >> 3) + tid % G, sub = tid / G;
     const int per = (V + nblk - 1) / nblk;
     const int v0 = blk * per, v1 = min(V, v0 + per);
     float m[8], r[8], sc[8], acc[8];
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, 
         for (int off = SUB >> 1; off > 0; off >>= 1) {
             if (sub < off) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sh[tid * 8 + j] += sh[((sub + off) * G + g) * 8 + j];
+                for (int j = 0; j < 8; ++j) sh[tid * 8 + j] += sh[(tid + off * G) * 8 + j];
             }
             __syncthreads();
         }
@@ -246,9 +247,9 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, 
 void launch_prep(const float* x, int B, int V, int C, const float* mean, const float* rstd, int relu,
                  const float* scale, SplitView out, float* out_raw, float* gap, float* ws, int* errflag,
                  hipStream_t st) {
-    int G = C / 8, SUB = 256 / G;
+    int Cs = C < 64 ? C : 64, G = Cs / 8, SUB = 256 / G;
     int nblk = pick_blocks(V, SUB * 4, gap ? RED_BLOCKS : 4096);
-    hipLaunchKernelGGL(prep_kernel, dim3(nblk, B), dim3(256), 256 * 8 * sizeof(float), st, x, V, C, mean, rstd, relu,
+    hipLaunchKernelGGL(prep_kernel, dim3(nblk, B, C / Cs), dim3(256), 256 * 8 * sizeof(float), st, x, V, C, mean, rstd, relu,
                        scale, out, out_raw, gap ? ws : nullptr, errflag);
     if (gap) launch_finalize_sum(ws, B, nblk, C, 1.0f / (float)V, gap, st);
 }
@@ -266,8 +267,9 @@ __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict_
                                                         SplitView plain, float* __restrict__ ws, int* __restrict__ errflag) {
     extern __shared__ float sh[];
     const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
-    const int G = C >> 3, SUB = 256 / G;
-    const int tid = threadIdx.x, g = tid % G, sub = tid / G;
+    const int Cs = C < 64 ? C : 64;                 // channel slab per block (see prep_kernel)
+    const int G = Cs >> 3, SUB = 256 / G;
+    const int tid = threadIdx.x, g = blockIdx.z * (Cs >> 3) + tid % G, sub = tid / G;
     const int Wh = (d.W + 1) >> 1;
     const int V = d.D * d.H * d.W, Vh = d.D * d.H * Wh;
     const int per = (Vh + nblk - 1) / nblk;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict_
         for (int off = SUB >> 1; off > 0; off >>= 1) {
             if (sub < off) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sh[tid * 8 + j] += sh[((sub + off) * G + g) * 8 + j];
+                for (int j = 0; j < 8; ++j) sh[tid * 8 + j] += sh[(tid + off * G) * 8 + j];
             }
             __syncthreads();
         }
@@ -354,10 +356,10 @@ __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict_
 
 void launch_prep_wino(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, int relu, const float* scale,
                       SplitView wino, SplitView plain, float* gap, float* ws, int* errflag, hipStream_t st) {
-    int G = C / 8, SUB = 256 / G;
+    int Cs = C < 64 ? C : 64, G = Cs / 8, SUB = 256 / G;
     int Vh = d.D * d.H * ((d.W + 1) / 2);
     int nblk = pick_blocks(Vh, SUB * 2, gap ? RED_BLOCKS : 4096);
-    hipLaunchKernelGGL(prep_wino_kernel, dim3(nblk, B), dim3(256), 256 * 8 * sizeof(float), st, x, d, C, mean, rstd, relu, scale,
+    hipLaunchKernelGGL(prep_wino_kernel, dim3(nblk, B, C / Cs), dim3(256), 256 * 8 * sizeof(float), st, x, d, C, mean, rstd, relu, scale,
                        wino, plain, gap ? ws : nullptr, errflag);
     if (gap) launch_finalize_sum(ws, B, nblk, C, 1.0f / (float)(d.D * d.H * d.W), gap, st);
 }
