@@ -74,7 +74,7 @@ void launch_gate_mlp(const float* pool, const float* premul, int B, int C, int C
 void launch_fill_float(float* p, int64_t n, float v, hipStream_t st);
 
 // depthwise 3^3 on raw input with fused (x-mean)*rstd, relu, *scale applied on load (zero padding after)
-// C must be a multiple of 32.  stats_ws (nullable): fused InstanceNorm partials, returns their count P.
+// C must be a multiple of 16.  stats_ws (nullable): fused InstanceNorm partials, returns their count P.
 int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, hipStream_t st);
 // merge P partials f32 [B][P][C][3] = (count, mean, M2) into mean / rstd

@@ -802,8 +802,8 @@ int mica_op_instnorm_relu(mica_ctx* c, const float* d_x, int batch, int ch, int 
 int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, int h, int w, const float* h_w, const float* h_b,
                        float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
-    if (!d_x || !d_y || !h_w || !h_b || batch < 1 || ch < 32 || ch % 32 || d < 1 || h < 1 || w < 1) {
-        c->err = "mica_op_depthwise3: bad argument (C must be a multiple of 32)";
+    if (!d_x || !d_y || !h_w || !h_b || batch < 1 || ch < 16 || ch % 16 || d < 1 || h < 1 || w < 1) {
+        c->err = "mica_op_depthwise3: bad argument (C must be a multiple of 16)";
         return MICA_ERR_ARG;
     }
     HIPC(c, hipSetDevice(c->device));

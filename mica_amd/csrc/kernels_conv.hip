@@ -846,88 +846,126 @@ void launch_pack_weights(const float* w, int cout, int cin, int ksize, const int
 //   y = scale[c] * relu((x - mean[c]) * rstd[c]);  out = sum_tap w[tap][c] * y(shifted, zero padded) + bias
 // HBM-bound (8 B/voxel/channel algorithmic); the 27 shifted reads are served by L1/L2.
 // ------------------------------------------------------------------------------------------------
-constexpr int DW_RUN = 8;   // consecutive x outputs per thread
-__global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict__ x, Dims d, int C,
+// One workgroup = 16 channels x a 16(x) x 16(y) column of the tile, marching along z with a ring of three
+// halo'd z planes in LDS (18 x 18 voxels x 16 channels x 4 B = 20.7 KB each): every input element is read from HBM
+// once per column (x/y halo 1.27x, no z re-reads), normalised once when it enters the ring, and the 27 taps
+// come from LDS.  Thread = (channel quad, x, 4 consecutive y) with a sliding window along y.
+constexpr int DW_X = 16, DW_Y = 16, DW_C = 16;
+constexpr int DW_LX = DW_X + 2, DW_LY = DW_Y + 2;
+constexpr int DW_PLANE = DW_LX * DW_LY * DW_C;     // floats per ring plane
+
+__global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restrict__ x, Dims d, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ scale, const float* __restrict__ w27,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        float* __restrict__ stats_ws) {
-    extern __shared__ float sh[];   // [3][256][4] statistics merge
+                                                        float* __restrict__ stats_ws, int ntx, int nty) {
+    extern __shared__ __attribute__((aligned(16))) float ring[];   // [3][LY][LX][16] ; reused for the statistics merge
     const int b = blockIdx.y;
     const int V = d.D * d.H * d.W;
-    // A block = 32 channels x 32 x-runs.  Blocks are ordered channel-block outermost and each XCD gets a
-    // contiguous range of them, so the three z planes a run reads (0.5 MB per plane at 32 channels) stay in that
-    // XCD's L2 instead of being re-fetched from HBM (7.5x read amplification measured with all channels per block).
-    constexpr int CG = 8, RPB = 32;
-    const int tid = threadIdx.x, cg = tid & 7, rl = tid >> 3;
-    const int nruns_x = (d.W + DW_RUN - 1) / DW_RUN;
-    const int nruns = d.D * d.H * nruns_x;
-    const int nrb = (nruns + RPB - 1) / RPB;
+    const int tid = threadIdx.x;
+    // block order: channel slab outermost, XCD-contiguous (neighbouring columns share halos in one L2)
     int id = blockIdx.x;
     const int nwg = gridDim.x;
     if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
-    const int cblk = id / nrb, rb = id - cblk * nrb;
-    const int run = rb * RPB + rl;
-    const int c = cblk * 32 + cg * 4;
-    float4 m = make_float4(0, 0, 0, 0), r = make_float4(1, 1, 1, 1), sc = make_float4(1, 1, 1, 1);
-    if (mean) { m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c); r = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c); }
-    if (scale) sc = *reinterpret_cast<const float4*>(scale + (int64_t)b * C + c);
+    const int ncol = ntx * nty;
+    const int cs = id / ncol, col = id - cs * ncol;
+    const int tx = col % ntx, ty = col / ntx;
+    const int x0 = tx * DW_X, y0 = ty * DW_Y, c0 = cs * DW_C;
+
+    const int cq = tid & 3, xi = (tid >> 2) & 15, yq = tid >> 6;     // compute role: 4 channels, x, 4 y outputs
+    const int c = c0 + cq * 4;
+    float* wl = ring + 3 * DW_PLANE;                                  // [27][16] weights of this channel slab
+    for (int e = tid; e < 27 * DW_C; e += 256) wl[e] = w27[(e >> 4) * C + c0 + (e & 15)];
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+
+    // load role: plane elements (voxel, channel quad): 324 voxels x 4 quads = 1296 float4 per plane, <= 6 per thread.
+    // A plane is fetched into registers one step ahead (HBM latency hides under the previous plane's FMAs),
+    // normalised once, and written to the ring slot of the plane that has just been retired.
+    constexpr int NE = (DW_LX * DW_LY * 4 + 255) / 256;
+    float4 pre[NE];
+    // the channel quad of a thread's elements is (tid + 256 k) & 3 = tid & 3: one set of norm constants
+    const int lq = tid & 3;
+    float4 nm = make_float4(0, 0, 0, 0), nr = make_float4(1, 1, 1, 1), ns = make_float4(1, 1, 1, 1);
+    if (mean) { nm = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c0 + lq * 4); nr = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c0 + lq * 4); }
+    if (scale) ns = *reinterpret_cast<const float4*>(scale + (int64_t)b * C + c0 + lq * 4);
+    auto fetch_plane = [&](int gz) {
+        const bool zok = (unsigned)gz < (unsigned)d.D;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = tid + 256 * k;
+            const int q = lq, v = e >> 2;
+            const int lx = v % DW_LX, ly = v / DW_LX;
+            const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+            const bool ok = zok && e < DW_LX * DW_LY * 4 && (unsigned)gx < (unsigned)d.W && (unsigned)gy < (unsigned)d.H;
+            const int cx = min(max(gx, 0), d.W - 1), cy = min(max(gy, 0), d.H - 1), cz = min(max(gz, 0), d.D - 1);
+            float4 t = *reinterpret_cast<const float4*>(x + ((int64_t)b * V + (int64_t)(cz * d.H + cy) * d.W + cx) * C + c0 + q * 4);
+            if (mean) {
+                t.x = fmaxf((t.x - nm.x) * nr.x, 0.f) * ns.x; t.y = fmaxf((t.y - nm.y) * nr.y, 0.f) * ns.y;
+                t.z = fmaxf((t.z - nm.z) * nr.z, 0.f) * ns.z; t.w = fmaxf((t.w - nm.w) * nr.w, 0.f) * ns.w;
+            } else { t.x *= ns.x; t.y *= ns.y; t.z *= ns.z; t.w *= ns.w; }
+            pre[k] = ok ? t : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto store_plane = [&](int slot) {
+        float* dst = ring + slot * DW_PLANE;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = tid + 256 * k;
+            if (e < DW_LX * DW_LY * 4) *reinterpret_cast<float4*>(dst + (e >> 2) * DW_C + (e & 3) * 4) = pre[k];
+        }
+    };
+
     float sn = 0.f;
     float4 sk = make_float4(0, 0, 0, 0), s1 = sk, s2 = sk;
-    if (run < nruns) {
-        const int xr = run % nruns_x, row = run / nruns_x;
-        const int yh = row % d.H, zd = row / d.H, x0 = xr * DW_RUN;
-        const float4 bv = *reinterpret_cast<const float4*>(bias + c);
-        float4 acc[DW_RUN];
+    fetch_plane(-1); store_plane(0);
+    fetch_plane(0);  store_plane(1);
+    fetch_plane(1);  store_plane(2);
+    __syncthreads();
+    for (int z = 0; z < d.D; ++z) {
+        fetch_plane(z + 2);                 // in flight during this plane's arithmetic
+        float4 acc[4];
 #pragma unroll
-        for (int i = 0; i < DW_RUN; ++i) acc[i] = bv;
-        const float* xb = x + (int64_t)b * V * C + c;
+        for (int i = 0; i < 4; ++i) acc[i] = bv;
+#pragma unroll 1
+        for (int dz = 0; dz < 3; ++dz) {
+            const float* pl = ring + ((z + dz) % 3) * DW_PLANE + (xi * DW_C + cq * 4);
+#pragma unroll 1
+            for (int dx = 0; dx < 3; ++dx) {
+                float4 win[6];
 #pragma unroll
-        for (int dz = -1; dz <= 1; ++dz)
+                for (int i = 0; i < 6; ++i)
+                    win[i] = *reinterpret_cast<const float4*>(pl + ((yq * 4 + i) * DW_LX + dx) * DW_C);
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int zz = zd + dz, yy = yh + dy;
-                if ((unsigned)zz < (unsigned)d.D && (unsigned)yy < (unsigned)d.H) {
-                    const float* rowp = xb + ((int64_t)(zz * d.H + yy) * d.W) * C;
-                    float4 win[DW_RUN + 2];
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float4 w = *reinterpret_cast<const float4*>(wl + ((dz * 3 + dy) * 3 + dx) * DW_C + cq * 4);
 #pragma unroll
-                    for (int i = 0; i < DW_RUN + 2; ++i) {
-                        const int xx = x0 - 1 + i;
-                        const bool ok = (unsigned)xx < (unsigned)d.W;
-                        float4 t = *reinterpret_cast<const float4*>(rowp + (int64_t)(ok ? xx : x0) * C);
-                        if (mean) {
-                            t.x = fmaxf((t.x - m.x) * r.x, 0.f) * sc.x; t.y = fmaxf((t.y - m.y) * r.y, 0.f) * sc.y;
-                            t.z = fmaxf((t.z - m.z) * r.z, 0.f) * sc.z; t.w = fmaxf((t.w - m.w) * r.w, 0.f) * sc.w;
-                        } else { t.x *= sc.x; t.y *= sc.y; t.z *= sc.z; t.w *= sc.w; }
-                        win[i] = ok ? t : make_float4(0, 0, 0, 0);
-                    }
-                    const int tap0 = ((dz + 1) * 3 + (dy + 1)) * 3;
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const float4 wv = *reinterpret_cast<const float4*>(w27 + (tap0 + dx) * C + c);
-#pragma unroll
-                        for (int i = 0; i < DW_RUN; ++i) {
-                            acc[i].x = fmaf(wv.x, win[i + dx].x, acc[i].x); acc[i].y = fmaf(wv.y, win[i + dx].y, acc[i].y);
-                            acc[i].z = fmaf(wv.z, win[i + dx].z, acc[i].z); acc[i].w = fmaf(wv.w, win[i + dx].w, acc[i].w);
-                        }
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i].x = fmaf(w.x, win[i + dy].x, acc[i].x); acc[i].y = fmaf(w.y, win[i + dy].y, acc[i].y);
+                        acc[i].z = fmaf(w.z, win[i + dy].z, acc[i].z); acc[i].w = fmaf(w.w, win[i + dy].w, acc[i].w);
                     }
                 }
             }
-        float* ob = out + ((int64_t)b * V + (int64_t)(zd * d.H + yh) * d.W) * C + c;
+        }
+        const int gx = x0 + xi;
 #pragma unroll
-        for (int i = 0; i < DW_RUN; ++i)
-            if (x0 + i < d.W) {
-                *reinterpret_cast<float4*>(ob + (int64_t)(x0 + i) * C) = acc[i];
+        for (int i = 0; i < 4; ++i) {
+            const int gy = y0 + yq * 4 + i;
+            if (gx < d.W && gy < d.H) {
+                *reinterpret_cast<float4*>(out + ((int64_t)b * V + (int64_t)(z * d.H + gy) * d.W + gx) * C + c) = acc[i];
                 if (sn == 0.f) sk = acc[i];
                 const float4 t = make_float4(acc[i].x - sk.x, acc[i].y - sk.y, acc[i].z - sk.z, acc[i].w - sk.w);
                 s1.x += t.x; s1.y += t.y; s1.z += t.z; s1.w += t.w;
                 s2.x = fmaf(t.x, t.x, s2.x); s2.y = fmaf(t.y, t.y, s2.y); s2.z = fmaf(t.z, t.z, s2.z); s2.w = fmaf(t.w, t.w, s2.w);
                 sn += 1.f;
             }
+        }
+        __syncthreads();                    // plane z-1 (slot z % 3) is no longer read by anyone
+        store_plane(z % 3);                 // plane z+2 takes its place
+        __syncthreads();
     }
     if (!stats_ws) return;
-    // block merge of (count, mean, M2) over the x-runs, then one partial per block and channel
-    float* shn = sh; float* shm = sh + 1024; float* shq = sh + 2048;
+    // block merge of (count, mean, M2): 64 threads (x, yq) share a channel quad
+    float* shn = ring; float* shm = ring + 1024; float* shq = ring + 2048;
     const float kk[4] = {sk.x, sk.y, sk.z, sk.w}, a1[4] = {s1.x, s1.y, s1.z, s1.w}, a2[4] = {s2.x, s2.y, s2.z, s2.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -936,9 +974,10 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict_
         shn[tid * 4 + j] = sn; shm[tid * 4 + j] = mean_; shq[tid * 4 + j] = m2;
     }
     __syncthreads();
-    for (int off = RPB >> 1; off > 0; off >>= 1) {
+    const int rl = tid >> 2;                       // 0..63 within the channel quad
+    for (int off = 32; off > 0; off >>= 1) {
         if (rl < off) {
-            const int o = (rl + off) * CG + cg;
+            const int o = tid + off * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float na = shn[tid * 4 + j], ma = shm[tid * 4 + j], qa = shq[tid * 4 + j];
@@ -953,7 +992,7 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict_
         __syncthreads();
     }
     if (rl == 0) {
-        float* wsp = stats_ws + (((int64_t)b * nrb + rb) * C + c) * 3;
+        float* wsp = stats_ws + (((int64_t)b * ncol + col) * C + c) * 3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { wsp[j * 3] = shn[tid * 4 + j]; wsp[j * 3 + 1] = shm[tid * 4 + j]; wsp[j * 3 + 2] = shq[tid * 4 + j]; }
     }
@@ -962,14 +1001,12 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const float* __restrict_
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null).
 int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, hipStream_t st) {
-    const int nruns = d.D * d.H * ((d.W + DW_RUN - 1) / DW_RUN);
-    const int nrb = (nruns + 31) / 32;
-    dim3 grid((unsigned)(nrb * (C / 32)), B);
-    hipLaunchKernelGGL(depthwise_kernel, grid, dim3(256), 3 * 1024 * sizeof(float), st, x, d, C, mean, rstd, scale, w27, bias, out,
-                       stats_ws);
-    return nrb;
+    const int ntx = (d.W + DW_X - 1) / DW_X, nty = (d.H + DW_Y - 1) / DW_Y;
+    dim3 grid((unsigned)(ntx * nty * (C / DW_C)), B);
+    const size_t lds = (3 * DW_PLANE + 27 * DW_C) * sizeof(float);
+    hipLaunchKernelGGL(depthwise_kernel, grid, dim3(256), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty);
+    return ntx * nty;
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // Multi-scale stem (model.py:9-14,49-51): four Conv3d(1,32,k) with k = 3,5,7,9 on the density tile.
