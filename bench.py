@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--pad", type=int, default=16)
     ap.add_argument("--no-af", action="store_true", help="zero-AF path (exp_downsizing branch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse N>1 on one GPU")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
     import numpy as np
@@ -62,10 +64,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     n = args.map or (256 if world == 1 else 512)
     B = args.batch
@@ -94,7 +101,12 @@ def main():
             eng.stitch_tiles(rec, out, args.grid, p, first)
         else:
             crop = rec[:, :, p:p + g3, p:p + g3, p:p + g3].contiguous()
-            dist.all_gather_into_tensor(gathered, crop)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, crop)
+            else:                                   # gloo rehearsal: stage through the host
+                parts = [torch.empty(crop.shape, dtype=crop.dtype) for _ in range(world)]
+                dist.all_gather(parts, crop.cpu())
+                gathered.copy_(torch.cat(parts).to(dev))
             if rank == 0:
                 # cropped records carry no halo: stitch them with pad 0 on a grid-sized window
                 for r in range(world):
@@ -116,7 +128,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     tiles = args.steps * B * world

@@ -62,11 +62,24 @@ class GridCreator:
             yield first, eng.gather_tiles(v, grid_size, padding, first, count)
 
     # ---- file-writing form (same artefacts as the reference) ------------------------------------------
-    def create_grids_from_mrc(self, mrc_file, output_dir, grid_size=48, padding=8, file_prefix="grid"):
+    def create_and_save_grids(self, mrc_file, output_dir, grid_size=48, padding=8, min_grid_max=None):
+        """The training-data tilers (scripts_for_training_data/create_grids_for_normalized_map.py:18-101 and its
+        four siblings): same pad/loop as the inference tiler but WITHOUT the axis transpose, file prefix
+        `grid_`; the normalised-map variant skips tiles whose maximum is below 0.01 (:78) - pass
+        min_grid_max=0.01 for that one, None for the mask/encoding variants.  Returns the number of files."""
+        return self.create_grids_from_mrc(mrc_file, output_dir, grid_size, padding, "grid", transpose=False,
+                                          min_grid_max=min_grid_max)[0]
+
+    def create_grids_from_mrc(self, mrc_file, output_dir, grid_size=48, padding=8, file_prefix="grid", transpose=True,
+                              min_grid_max=None):
         """create_grids.py:89-184: returns (grid_count, offset); (0, None) on failure."""
         try:
             os.makedirs(output_dir, exist_ok=True)
-            vol, offset, hd = self.load_volume(mrc_file)
+            if transpose:
+                vol, offset, hd = self.load_volume(mrc_file)
+            else:
+                data, hd = mrc.read_mrc(mrc_file)
+                vol, offset = np.ascontiguousarray(data), [float(hd.nzstart), float(hd.nystart), float(hd.nxstart)]
             orig_shape = vol.shape
             from ._cabi import tile_table
             table = tile_table(*orig_shape, grid_size)
@@ -77,6 +90,8 @@ class GridCreator:
             for first, tiles in self.tiles_on_device(vol.astype(np.float32), grid_size, padding):
                 host = tiles.cpu().numpy()[:, 0]
                 for t in range(host.shape[0]):
+                    if min_grid_max is not None and host[t].max() < min_grid_max:
+                        continue
                     i, j, k, di, dj, dk = (int(x) for x in table[first + t])
                     np.savez(os.path.join(output_dir, f"{file_prefix}_i{i}_j{j}_k{k}.npz"),
                              grid=host[t].astype(src_dtype, copy=False), i=i, j=j, k=k, di=di, dj=dj, dk=dk,

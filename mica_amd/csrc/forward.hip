@@ -439,6 +439,17 @@ bool pow2_8_512(int c) { return c >= 8 && c <= 512 && (c & (c - 1)) == 0; }
 }  // namespace
 
 
+// range check of the split-f16 encoding: fail loudly rather than return clipped activations (synchronises `st`)
+static int check_range(mica_ctx* c, hipStream_t st) {
+    HIPC(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPC(c, hipStreamSynchronize(st));
+    if (*c->h_err) {
+        c->err = "activation outside the representable range of the split-f16 conv path (|x| > 3750, or NaN/Inf in the input)";
+        return MICA_ERR_RANGE;
+    }
+    return MICA_OK;
+}
+
 // =================================================================================================
 extern "C" {
 
@@ -640,7 +651,8 @@ int mica_forward_logits(mica_ctx* c, const float* d_map, const float* d_af, int 
     if (!c) return MICA_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     int r = forward_impl(c, d_map, d_af, batch, af_mode, d_bb, d_ca, d_aa, st);
-    return r;
+    if (r) return r;
+    return check_range(c, st);
 }
 
 int mica_postprocess(mica_ctx* c, const float* d_bb, const float* d_ca, const float* d_aa, int batch, float* d_bb_prob,
@@ -661,11 +673,7 @@ int mica_forward_tiles(mica_ctx* c, const float* d_map, const float* d_af, int b
     if (r) return r;
     r = mica_postprocess(c, c->logits[0], c->logits[1], c->logits[2], batch, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, stream);
     if (r) return r;
-    // range check of the split-f16 encoding: fail loudly rather than return clipped activations
-    HIPC(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPC(c, hipStreamSynchronize(st));
-    if (*c->h_err) { c->err = "activation outside the representable range of the split-f16 conv path (|x| > 3750 or NaN)"; return MICA_ERR_RANGE; }
-    return MICA_OK;
+    return check_range(c, st);
 }
 
 int64_t mica_tile_count(int64_t n0, int64_t n1, int64_t n2, int grid) {
