@@ -532,12 +532,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
     const unsigned wlane = (unsigned)(lh * cout + (lane & 31)) * 16u;
 
     const int nsteps = total_chunks * G::NT;
-    half8 bnx[NJ][2];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int kind = 0; kind < 2; ++kind) bnx[j][kind] = *reinterpret_cast<const half8*>(wuni + kind * bkind + j * 512 + wlane);
-
+    // B fragments are fetched TWO steps ahead into a ring of three register sets (9 taps per chunk keep the ring
+    // phase constant): with one step of lead the waits behind the L2 (5 TB/s of weight traffic chip-wide) cost 25 %
+    // of the cycles (ablation: no-B-load build 4.6 M vs 6.06 M cycles).  The loads are inline asm with hand-counted
+    // waits: beside the LDS-DMA hipcc would drain vmcnt(0) at the fragments' first use, i.e. also the loads issued a
+    // few instructions earlier.  Per step and wave 2*NJ loads are issued; a step's fragments are two steps old when
+    // used, so `vmcnt(4*NJ)` (the two younger steps; LDS-DMA issued in between only makes the wait stricter) retires them.
+    half8 bq[3][NJ][2];
+    const char* wkind1 = wuni + bkind;
+#define MICA_BLOAD(set, step)                                                                                        \
+    do {                                                                                                             \
+        const char* p0_ = wuni + (int64_t)(step) * bstep;                                                            \
+        const char* p1_ = wkind1 + (int64_t)(step) * bstep;                                                          \
+        _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_) {                                                          \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][j_][0]) : "v"(wlane + j_ * 512u), "s"(p0_) : "memory"); \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][j_][1]) : "v"(wlane + j_ * 512u), "s"(p1_) : "memory"); \
+        }                                                                                                            \
+    } while (0)
+    MICA_BLOAD(0, 0);
+    MICA_BLOAD(1, nsteps > 1 ? 1 : 0);
     __syncthreads();
     issue_chunk_dma<G::DPW>(chunk_base_wino(s, 0, b, Vh), smem, goff, loff);
     __syncthreads();
@@ -554,17 +567,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
                 if (tap == 4 && wave >= 4) issue_chunk_dma<G::DPW>(chunk_base_wino(s, gch + 1, b, Vh), nxt, goff, loff);
             }
             const int dz = tap / 3, dy = tap % 3;
-            half8 bc[NJ][2];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) { bc[j][0] = bnx[j][0]; bc[j][1] = bnx[j][1]; }
-            if (g + 1 < nsteps) {
-                const char* wn_ = wuni + (int64_t)(g + 1) * bstep;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int kind = 0; kind < 2; ++kind)
-                        bnx[j][kind] = *reinterpret_cast<const half8*>(wn_ + kind * bkind + j * 512 + wlane);
-            }
+            half8 (&bc)[NJ][2] = bq[tap % 3];
+            // Always issued (the step index is clamped at the tail, a harmless re-read): straight-line code, so every
+            // asm load is consumed exactly two taps later on the only path and the 2*NJ*2 youngest loads are always
+            // the two younger steps.  tools/audit_asm_loads.py checks the emitted code for compiler accesses to
+            // in-flight destinations (tests/test_cpu_oracle.py runs it).
+            MICA_BLOAD((tap + 2) % 3, (g + 2 < nsteps) ? g + 2 : nsteps - 1);
+            if (NJ == 2) asm volatile("s_waitcnt vmcnt(8)" : "+v"(bc[0][0]), "+v"(bc[0][1]), "+v"(bc[NJ - 1][0]), "+v"(bc[NJ - 1][1]));
+            else asm volatile("s_waitcnt vmcnt(4)" : "+v"(bc[0][0]), "+v"(bc[0][1]));
+            __builtin_amdgcn_sched_barrier(0);
             half8 a[FM][2];
 #pragma unroll
             for (int f = 0; f < FM; ++f)
@@ -584,6 +595,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
         __syncthreads();
     }
 
+#undef MICA_BLOAD
+    // Drain the (redundant) tail loads and keep every ring register live up to here: a dead asm destination could be
+    // re-used by the compiler while its load is still in flight.
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[r][j][0]), "+v"(bq[r][j][1]));
     // ---- output transform through LDS: region [wn][zfrag 4][p 4][row 32][col 32] floats per j -------
     float* xs = reinterpret_cast<float*>(smem);
     const int col = lane & 31, rhalf = lane >> 5;

@@ -4,6 +4,7 @@ import hashlib
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -182,3 +183,33 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(ROOT, "mica_amd", fn)).read()
             assert "oracle" not in src, fn
+
+
+def test_inline_asm_weight_prefetch_is_hazard_free(tmp_path):
+    """conv_wino_kernel fetches its weight fragments with inline-asm loads and hand-counted s_waitcnt.  hipcc does not
+    model those loads, so the emitted code is audited: between an asm load and the wait that retires it no other
+    instruction may touch its destination registers (tools/audit_asm_loads.py); cross-compiles without a GPU."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "mica_amd", "csrc", "kernels_conv.hip")
+    asm = str(tmp_path / "kernels_conv.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", asm, src],
+                          stderr=subprocess.DEVNULL)
+    text = open(asm).read()
+    found = 0
+    for variant, keep in (("ILi128ELi2E", 8), ("ILi64ELi2E", 4), ("ILi32ELi1E", 4)):
+        m = re.search(r"^_ZN4mica16conv_wino_kernel" + variant + r".*?s_endpgm", text, flags=re.S | re.M)
+        assert m, variant
+        part = str(tmp_path / (variant + ".s"))
+        open(part, "w").write(m.group(0))
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), part, str(keep)], text=True)
+        assert "violations: 0" in out, out[-2000:]
+        assert m.group(0).count("global_load_dwordx4") >= 18 and ".vgpr_spill_count" not in m.group(0)
+        found += 1
+    assert found == 3
+    # no kernel of the file spills (a spilled asm destination would be reloaded/stored around in-flight loads)
+    spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
+    assert spills and max(spills) == 0, spills
