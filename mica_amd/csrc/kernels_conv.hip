@@ -560,12 +560,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
         const char* A = smem + (gch & 1) * G::CH_BYTES + a_base;
         char* nxt = smem + ((gch + 1) & 1) * G::CH_BYTES;
         const bool have_next = gch + 1 < total_chunks;
+        const _Float16* nsrc = chunk_base_wino(s, have_next ? gch + 1 : gch, b, Vh);
 #pragma unroll
         for (int tap = 0; tap < G::NT; ++tap, ++g) {
-            if (have_next) {
-                if (tap == 0 && wave < 4) issue_chunk_dma<G::DPW>(chunk_base_wino(s, gch + 1, b, Vh), nxt, goff, loff);
-                if (tap == 4 && wave >= 4) issue_chunk_dma<G::DPW>(chunk_base_wino(s, gch + 1, b, Vh), nxt, goff, loff);
-            }
             const int dz = tap / 3, dy = tap % 3;
             half8 (&bc)[NJ][2] = bq[tap % 3];
             // Always issued (the step index is clamped at the tail, a harmless re-read): straight-line code, so every
@@ -576,6 +573,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
             if (NJ == 2) asm volatile("s_waitcnt vmcnt(8)" : "+v"(bc[0][0]), "+v"(bc[0][1]), "+v"(bc[NJ - 1][0]), "+v"(bc[NJ - 1][1]));
             else asm volatile("s_waitcnt vmcnt(4)" : "+v"(bc[0][0]), "+v"(bc[0][1]));
             __builtin_amdgcn_sched_barrier(0);
+            // One LDS-DMA instruction of the next chunk per tap (DPW = 9 = taps): vmcnt retires in order, so a burst of
+            // nine DMAs in front of a fragment wait would stall it for a full HBM round trip; one per tap, issued after
+            // the wait, is at least a tap old by the time a later wait has to pass it.
+            if (have_next && goff[tap] >= 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc + goff[tap]),
+                                                 (__attribute__((address_space(3))) void*)(nxt + loff[tap]), 16, 0, 0);
             half8 a[FM][2];
 #pragma unroll
             for (int f = 0; f < FM; ++f)
