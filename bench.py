@@ -39,9 +39,9 @@ def cpu_baseline(weights, tile_map, tile_af, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--map", type=int, default=0, help="map edge (default 256 at N=1, 512 at N>1)")
     ap.add_argument("--grid", type=int, default=32)
     ap.add_argument("--pad", type=int, default=16)

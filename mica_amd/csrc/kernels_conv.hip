@@ -871,16 +871,22 @@ void launch_pack_weights(const float* w, int cout, int cin, int ksize, const int
 // halo'd z planes in LDS (18 x 18 voxels x 16 channels x 4 B = 20.7 KB each): every input element is read from HBM
 // once per column (x/y halo 1.27x, no z re-reads), normalised once when it enters the ring, and the 27 taps
 // come from LDS.  Thread = (channel quad, x, 4 consecutive y) with a sliding window along y.
-constexpr int DW_X = 16, DW_Y = 16, DW_C = 16;
-constexpr int DW_LX = DW_X + 2, DW_LY = DW_Y + 2;
-constexpr int DW_PLANE = DW_LX * DW_LY * DW_C;     // floats per ring plane
+constexpr int DW_X = 16, DW_C = 16;
+constexpr int DW_LX = DW_X + 2;
+// YO = y outputs per thread: the column is 16(x) x 4*YO(y); YO = 2 doubles the number of workgroups for small C * batch
+template <int YO> struct DwGeo {
+    static constexpr int Y = 4 * YO, LY = Y + 2;
+    static constexpr int PLANE = DW_LX * LY * DW_C;     // floats per ring plane
+};
 
+template <int YO>
 __global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restrict__ x, Dims d, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ scale, const float* __restrict__ w27,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         float* __restrict__ stats_ws, int ntx, int nty) {
     extern __shared__ __attribute__((aligned(16))) float ring[];   // [3][LY][LX][16] ; reused for the statistics merge
+    constexpr int DW_Y = DwGeo<YO>::Y, DW_LY = DwGeo<YO>::LY, DW_PLANE = DwGeo<YO>::PLANE;
     const int b = blockIdx.y;
     const int V = d.D * d.H * d.W;
     const int tid = threadIdx.x;
@@ -893,7 +899,7 @@ __global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restri
     const int tx = col % ntx, ty = col / ntx;
     const int x0 = tx * DW_X, y0 = ty * DW_Y, c0 = cs * DW_C;
 
-    const int cq = tid & 3, xi = (tid >> 2) & 15, yq = tid >> 6;     // compute role: 4 channels, x, 4 y outputs
+    const int cq = tid & 3, xi = (tid >> 2) & 15, yq = tid >> 6;     // compute role: 4 channels, x, YO y outputs
     const int c = c0 + cq * 4;
     float* wl = ring + 3 * DW_PLANE;                                  // [27][16] weights of this channel slab
     for (int e = tid; e < 27 * DW_C; e += 256) wl[e] = w27[(e >> 4) * C + c0 + (e & 15)];
@@ -944,23 +950,23 @@ __global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restri
     __syncthreads();
     for (int z = 0; z < d.D; ++z) {
         fetch_plane(z + 2);                 // in flight during this plane's arithmetic
-        float4 acc[4];
+        float4 acc[YO];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = bv;
+        for (int i = 0; i < YO; ++i) acc[i] = bv;
 #pragma unroll 1
         for (int dz = 0; dz < 3; ++dz) {
             const float* pl = ring + ((z + dz) % 3) * DW_PLANE + (xi * DW_C + cq * 4);
 #pragma unroll 1
             for (int dx = 0; dx < 3; ++dx) {
-                float4 win[6];
+                float4 win[YO + 2];
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
-                    win[i] = *reinterpret_cast<const float4*>(pl + ((yq * 4 + i) * DW_LX + dx) * DW_C);
+                for (int i = 0; i < YO + 2; ++i)
+                    win[i] = *reinterpret_cast<const float4*>(pl + ((yq * YO + i) * DW_LX + dx) * DW_C);
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const float4 w = *reinterpret_cast<const float4*>(wl + ((dz * 3 + dy) * 3 + dx) * DW_C + cq * 4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < YO; ++i) {
                         acc[i].x = fmaf(w.x, win[i + dy].x, acc[i].x); acc[i].y = fmaf(w.y, win[i + dy].y, acc[i].y);
                         acc[i].z = fmaf(w.z, win[i + dy].z, acc[i].z); acc[i].w = fmaf(w.w, win[i + dy].w, acc[i].w);
                     }
@@ -969,8 +975,8 @@ __global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restri
         }
         const int gx = x0 + xi;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gy = y0 + yq * 4 + i;
+        for (int i = 0; i < YO; ++i) {
+            const int gy = y0 + yq * YO + i;
             if (gx < d.W && gy < d.H) {
                 *reinterpret_cast<float4*>(out + ((int64_t)b * V + (int64_t)(z * d.H + gy) * d.W + gx) * C + c) = acc[i];
                 if (sn == 0.f) sk = acc[i];
@@ -1022,10 +1028,19 @@ __global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restri
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null).
 int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, hipStream_t st) {
-    const int ntx = (d.W + DW_X - 1) / DW_X, nty = (d.H + DW_Y - 1) / DW_Y;
+    const int ntx = (d.W + DW_X - 1) / DW_X;
+    // enough workgroups to fill 256 CUs twice: halve the column height when C * batch is small
+    const bool small = (int64_t)ntx * ((d.H + 15) / 16) * (C / DW_C) * B < 1024;
+    const int Y = small ? 8 : 16;
+    const int nty = (d.H + Y - 1) / Y;
     dim3 grid((unsigned)(ntx * nty * (C / DW_C)), B);
-    const size_t lds = (3 * DW_PLANE + 27 * DW_C) * sizeof(float);
-    hipLaunchKernelGGL(depthwise_kernel, grid, dim3(256), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty);
+    if (small) {
+        const size_t lds = (3 * DwGeo<2>::PLANE + 27 * DW_C) * sizeof(float);
+        hipLaunchKernelGGL(depthwise_kernel<2>, grid, dim3(256), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty);
+    } else {
+        const size_t lds = (3 * DwGeo<4>::PLANE + 27 * DW_C) * sizeof(float);
+        hipLaunchKernelGGL(depthwise_kernel<4>, grid, dim3(256), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty);
+    }
     return ntx * nty;
 }
 

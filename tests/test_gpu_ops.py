@@ -79,9 +79,10 @@ def test_instnorm_relu(eng, c, dims):
     assert float((got.cpu() - ref).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("c,dims", [(64, (8, 8, 8)), (128, (6, 9, 11)), (256, (8, 8, 8))])
-def test_depthwise(eng, c, dims):
-    x = _rand((2, c, *dims), 8)
+@pytest.mark.parametrize("c,dims,batch", [(64, (8, 8, 8), 2), (128, (6, 9, 11), 2), (256, (8, 8, 8), 2),
+                                          (256, (6, 64, 64), 4)])      # the last one takes the tall-column (YO = 4) variant
+def test_depthwise(eng, c, dims, batch):
+    x = _rand((batch, c, *dims), 8)
     w = _rand((c, 1, 3, 3, 3), 9) * 0.3
     b = _rand((c,), 10) * 0.1
     ref = F.conv3d(x, w, b, padding=1, groups=c)
