@@ -95,6 +95,13 @@ int mica_stitch_tiles(mica_ctx* ctx, const float* d_tiles, int channels, int64_t
  * reports "No positive values" / "Percentile value is zero" (preprocessing.py:159-165).      */
 int mica_normalise_map(mica_ctx* ctx, float* d_vol, int64_t n, double* h_stats, void* stream);
 
+/* ---- resampler: scipy.ndimage.zoom(data, factors, order=3) as called at preprocessing.py:117 ---- */
+/* d_in f32[n0][n1][n2] -> d_out f32[o0][o1][o2], o = int(round(n * factor)) chosen by the caller exactly as scipy does
+ * (mode='constant', cval=0, prefilter=True, grid_mode=False).  f64 internally, bit-exact against scipy 1.15.3.
+ * Synchronous; allocates an f64 copy of the input for the call.                                   */
+int mica_zoom_cubic(mica_ctx* ctx, const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1,
+                    int64_t o2, float* d_out, void* stream);
+
 /* ---- single-op entry points (parity tests drive each kernel through the ABI) -------------- */
 /* Conv3d k in {1,3}, stride 1, 'same' zero padding, on the split-f16 MFMA path.
  * d_x f32[B][Cin][D][H][W] NCDHW, h_w f32[Cout][Cin][k][k][k], h_b f32[Cout] -> d_y f32[B][Cout][D][H][W]. */

@@ -740,6 +740,22 @@ int mica_normalise_map(mica_ctx* c, float* d_vol, int64_t n, double* h_stats, vo
     return r;
 }
 
+int mica_zoom_cubic(mica_ctx* c, const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1, int64_t o2,
+                    float* d_out, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    const int64_t lim = 4096;
+    if (!d_in || !d_out || n0 < 1 || n1 < 1 || n2 < 1 || o0 < 1 || o1 < 1 || o2 < 1 || n0 > lim || n1 > lim || n2 > lim || o0 > lim ||
+        o1 > lim || o2 > lim) {
+        c->err = "mica_zoom_cubic: bad argument";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    char buf[256] = {0};
+    int r = zoom_cubic_device(d_in, n0, n1, n2, o0, o1, o2, d_out, (hipStream_t)stream, buf, sizeof(buf));
+    if (r) c->err = buf;
+    return r;
+}
+
 // ---- single-op entry points (test harness for the individual kernels) ---------------------------
 int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w, const float* h_b,
                    int cout, int k, float* d_y, void* stream) {

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
                                                            float* __restrict__ out, Dims d, int cout, int total_chunks,
                                                            int ntx, int nty, int nnb, float* __restrict__ stats_ws) {
     using G = GeoW;
-    constexpr int WM = 8 / WN;                     // 4 (positions) when WN = 2 ; WN = 1 => 8 waves = 4 positions x 2 z-halves
+    // WN = 2: 8 waves = 4 positions x 2 channel halves ; WN = 1: 4 positions x 2 z-halves
     constexpr int FM = (WN == 2) ? 4 : 2;          // z fragments per wave
     constexpr int WNC = (WN == 2) ? BN / 2 : BN;
     constexpr int NJ = WNC / 32;

@@ -163,6 +163,19 @@ class Engine:
         self._check(self.lib.mica_normalise_map(self._h, _ptr(vol), vol.numel(), st, _stream()), "mica_normalise_map")
         return float(st[0]), float(st[1])
 
+    def zoom_cubic(self, vol: torch.Tensor, factors):
+        """scipy.ndimage.zoom(vol, factors, order=3) on the GPU (bit-exact); vol f32[N0,N1,N2] -> f32[round(N*f)]."""
+        vol = _f32c(vol, "vol")
+        n = tuple(vol.shape)
+        if len(n) != 3 or len(factors) != 3:
+            raise MicaHipError("zoom_cubic: 3-D volume and three factors expected")
+        o = tuple(int(round(a * b)) for a, b in zip(n, factors))        # scipy's output_shape rule
+        if min(o) < 1:
+            raise MicaHipError(f"zoom_cubic: empty output shape {o}")
+        out = torch.empty(o, dtype=torch.float32, device=self.device)
+        self._check(self.lib.mica_zoom_cubic(self._h, _ptr(vol), *n, *o, _ptr(out), _stream()), "mica_zoom_cubic")
+        return out
+
     # -- single ops (tests) -----------------------------------------------------------------------------
     def op_conv3d(self, x, w, b, k):
         x = _f32c(x, "x")

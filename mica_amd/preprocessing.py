@@ -3,8 +3,8 @@
 GPU (exact median / 99.9th-percentile select, libmica_hip.so) and writes
 <dirname(AF3_results)>/resampled_normalized_map.mrc.
 
-Scope note: the cubic-spline resample for voxel sizes other than 1 A is still scipy on the host (SURVEY.md
-8f rank 2); `create_AF3_encodings` (PDB -> 24 rasters, needs Bio.PDB) is outside this build."""
+The cubic-spline resample (scipy.ndimage.zoom(order=3), :117) also runs on the GPU (`mica_zoom_cubic`, f64, bit-exact
+against scipy).  `create_AF3_encodings` (PDB -> 24 rasters, needs Bio.PDB) is outside this build."""
 from __future__ import annotations
 
 import logging
@@ -35,16 +35,14 @@ class DataPreprocessor:
         """preprocessing.py:111-133 on an array: returns (float32 map in [0,1], median, percentile).
         Raises MicaHipError where the reference logs 'Normalization failed'."""
         zf = [voxel_size[0] / target_voxel_size, voxel_size[1] / target_voxel_size, voxel_size[2] / target_voxel_size]
-        if all(f == 1.0 for f in zf) and np.isfinite(data).all():
-            res = data          # zoom(order=3) with unit factors reproduces finite float32 input exactly
-        else:
-            from scipy.ndimage import zoom
-            res = zoom(data, zf, order=3)                                   # :117
         eng = self._engine or Engine(self._device, max_batch=1, tile_size=64)
         self._engine = eng
-        if res.dtype != np.float32:
-            raise MicaHipError(f"map dtype {res.dtype}: the GPU normaliser takes float32 (MRC mode 2) maps")
-        t = torch.from_numpy(np.ascontiguousarray(res)).to(eng.device)
+        if data.dtype != np.float32:
+            raise MicaHipError(f"map dtype {data.dtype}: the GPU resampler/normaliser takes float32 (MRC mode 2) maps")
+        t = torch.from_numpy(np.ascontiguousarray(data)).to(eng.device)
+        # the reference zooms unconditionally (:117); the kernel reproduces scipy bit for bit, including factor 1.0
+        # (identity on finite data, NaN spreading through the recursive prefilter otherwise)
+        t = eng.zoom_cubic(t, zf)
         med, pct = eng.normalise_map_(t)
         return t.cpu().numpy(), med, pct
 

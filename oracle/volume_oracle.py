@@ -56,6 +56,80 @@ def stitch_volume(tile_data, idx, orig_shape, padding=8):
     return vol
 
 
+SPLINE_POLE = float.fromhex("-0x1.126145e9ecd56p-2")     # correctly rounded sqrt(3) - 2 (what scipy uses)
+
+
+def _spline_prefilter_axis(c, axis):
+    c = np.moveaxis(c, axis, -1)
+    n = c.shape[-1]
+    if n >= 2:
+        z = SPLINE_POLE
+        c *= (1.0 - z) * (1.0 - 1.0 / z)
+        z_n_1 = z ** (n - 1)
+        c0 = c[..., 0] + z_n_1 * c[..., n - 1]
+        zi = z
+        for i in range(1, n - 1):
+            c0 = c0 + zi * (c[..., i] + z_n_1 * c[..., n - 1 - i])
+            zi *= z
+        c[..., 0] = c0 / (1.0 - z_n_1 * z_n_1)
+        for i in range(1, n):
+            c[..., i] += z * c[..., i - 1]
+        c[..., n - 1] = (z * c[..., n - 2] + c[..., n - 1]) * z / (z * z - 1.0)
+        for i in range(n - 2, -1, -1):
+            c[..., i] = z * (c[..., i + 1] - c[..., i])
+    return np.moveaxis(c, -1, axis)
+
+
+def zoom_cubic(data, factors):
+    """Restatement of scipy.ndimage.zoom(data, factors, order=3) (mode='constant', cval=0, prefilter=True,
+    grid_mode=False) - the call at utils/preprocessing.py:117.  scipy is a third-party dependency of the reference
+    (environment.yml:13 pins 1.5.2, this image has 1.15.3) whose C source is not in the tree; this follows the published
+    algorithm and is pinned bit-exact against scipy 1.15.3 by tests/test_cpu_oracle.py.  float64 internally."""
+    import math
+    data = np.asarray(data)
+    n = data.shape
+    out_shape = tuple(int(round(a * b)) for a, b in zip(n, factors))
+    f = data.astype(np.float64)
+    for ax in range(3):
+        f = _spline_prefilter_axis(f, ax)
+    idx, wts, ok = [], [], []
+    for a in range(3):
+        zf = (n[a] - 1) / (out_shape[a] - 1) if out_shape[a] > 1 else 1.0
+        cc = np.arange(out_shape[a], dtype=np.float64) * zf
+        ok.append(~(cc > n[a] - 1))                       # scipy: a coordinate past the edge yields cval
+        fl = np.floor(cc)
+        x = cc - fl
+        y, zc = x, 1.0 - x
+        w1 = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0
+        w2 = (zc * zc * (zc - 2.0) * 3.0 + 4.0) / 6.0
+        w0 = zc * zc * zc / 6.0
+        w3 = 1.0 - w0 - w1 - w2
+        wts.append(np.stack([w0, w1, w2, w3]))
+        st = fl.astype(np.int64) - 1
+        ia = []
+        for k in range(4):
+            i = st + k
+            if n[a] == 1:
+                i = np.zeros_like(i)
+            else:
+                p = 2 * (n[a] - 1)
+                i = np.mod(i, p)
+                i = np.where(i < n[a], i, p - i)
+            ia.append(i)
+        idx.append(np.stack(ia))
+    out = np.zeros(out_shape, dtype=np.float64)
+    for k0 in range(4):
+        for k1 in range(4):
+            for k2 in range(4):
+                c = f[np.ix_(idx[0][k0], idx[1][k1], idx[2][k2])]
+                c = c * wts[0][k0][:, None, None]
+                c = c * wts[1][k1][None, :, None]
+                c = c * wts[2][k2][None, None, :]
+                out = out + c
+    out = out * (ok[0][:, None, None] & ok[1][None, :, None] & ok[2][None, None, :])
+    return out.astype(data.dtype if data.dtype.kind == "f" else np.float64)
+
+
 def normalise_map(data, voxel_size=(1.0, 1.0, 1.0), target_voxel_size=1.0):
     """utils/preprocessing.py:111-133 (second witness:
     scripts_for_training_data/create_normalized_map.py:37-79).  Returns (normalised f32 map,

@@ -213,3 +213,18 @@ def test_inline_asm_weight_prefetch_is_hazard_free(tmp_path):
     # no kernel of the file spills (a spilled asm destination would be reloaded/stored around in-flight loads)
     spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
     assert spills and max(spills) == 0, spills
+
+
+@pytest.mark.parametrize("shape,factors", [((6, 7, 5), (1.5, 1.25, 0.8)), ((9, 4, 11), (0.83, 0.83, 0.83)), ((5, 5, 5), (1.0, 1.0, 1.0)),
+                                           ((4, 1, 8), (47.0, 1.0, 0.5)), ((12, 10, 3), (1.07, 2.0, 1.3))])
+def test_zoom_restatement_is_bit_exact_vs_scipy(shape, factors):
+    """oracle.zoom_cubic restates scipy.ndimage.zoom(order=3) - the reference's resampler (preprocessing.py:117) - and
+    must agree with the installed scipy to the last bit, including the (4 -> 188) edge quirk where the last
+    coordinate rounds past the edge and scipy returns cval."""
+    from scipy.ndimage import zoom
+    x = (synth_density(shape, 17) - 0.3).astype(np.float32)
+    ref = zoom(x, factors, order=3)
+    got = vo.zoom_cubic(x, factors)
+    assert got.dtype == np.float32 and got.shape == ref.shape and np.array_equal(got, ref)
+    if shape == (4, 1, 8):
+        assert got.shape[0] == 188 and np.all(got[-1] == 0.0)      # scipy quirk reproduced
