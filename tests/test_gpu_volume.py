@@ -263,3 +263,24 @@ def test_preprocessor_with_anisotropic_voxels_and_nan(tmp_path, eng):
     from mica_amd.engine import MicaHipError
     with pytest.raises(MicaHipError, match="No positive values"):
         dp.normalize_array(bad, (1.0, 1.0, 1.0))
+
+
+def test_full_size_512_map_tiling_properties(eng):
+    """BASELINE configs[2] size: 512^3, reference tiling -> 1331 tiles; gather -> stitch is the identity and the
+    zero padding of the last window (pad_end = 64 - 512 % 48 = 48 voxels) is exact."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    vol = torch.rand((512, 512, 512), generator=g, device="cuda")
+    T = int(eng.lib.mica_tile_count(512, 512, 512, 48))
+    assert T == 1331
+    back = torch.zeros_like(vol)
+    for first in range(0, T, 121):
+        tiles = eng.gather_tiles(vol, 48, 8, first, 121)
+        eng.stitch_tiles(tiles, back, 48, 8, first)
+        if first + 121 == T:                                  # last tile: i=j=k=480, di=dj=dk=32
+            last = tiles[-1, 0]
+            assert torch.equal(last[8:40, 8:40, 8:40], vol[480:, 480:, 480:])
+            assert float(last[40:].abs().max()) == 0.0 and float(last[:, 40:].abs().max()) == 0.0
+    assert torch.equal(back, vol)
+    from mica_amd._cabi import tile_table
+    tab = tile_table(512, 512, 512, 48)
+    assert tab[-1].tolist() == [480, 480, 480, 32, 32, 32] and tab[0].tolist() == [0, 0, 0, 48, 48, 48]
