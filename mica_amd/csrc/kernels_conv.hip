@@ -538,7 +538,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
     // waits: beside the LDS-DMA hipcc would drain vmcnt(0) at the fragments' first use, i.e. also the loads issued a
     // few instructions earlier.  Per step and wave 2*NJ loads are issued; a step's fragments are two steps old when
     // used, so `vmcnt(4*NJ)` (the two younger steps; LDS-DMA issued in between only makes the wait stricter) retires them.
-    half8 bq[3][NJ][2];
+    // Ring depth: 3 sets (two taps of lead) when a wave owns two column fragments; with one (NJ == 1: 12 MFMAs per tap,
+    // kernels that are latency- not power-bound) registers allow 9 sets = eight taps of lead.
+    constexpr int RB = (NJ == 1) ? 9 : 3;
+    constexpr int LEAD = RB - 1;
+    half8 bq[RB][NJ][2];
     const char* wkind1 = wuni + bkind;
 #define MICA_BLOAD(set, step)                                                                                        \
     do {                                                                                                             \
@@ -549,8 +553,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][j_][1]) : "v"(wlane + j_ * 512u), "s"(p1_) : "memory"); \
         }                                                                                                            \
     } while (0)
-    MICA_BLOAD(0, 0);
-    MICA_BLOAD(1, nsteps > 1 ? 1 : 0);
+#pragma unroll
+    for (int r = 0; r < LEAD; ++r) MICA_BLOAD(r, r < nsteps ? r : nsteps - 1);
     __syncthreads();
     issue_chunk_dma<G::DPW>(chunk_base_wino(s, 0, b, Vh), smem, goff, loff);
     __syncthreads();
@@ -564,14 +568,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
 #pragma unroll
         for (int tap = 0; tap < G::NT; ++tap, ++g) {
             const int dz = tap / 3, dy = tap % 3;
-            half8 (&bc)[NJ][2] = bq[tap % 3];
+            half8 (&bc)[NJ][2] = bq[tap % RB];
             // Always issued (the step index is clamped at the tail, a harmless re-read): straight-line code, so every
             // asm load is consumed exactly two taps later on the only path and the 2*NJ*2 youngest loads are always
             // the two younger steps.  tools/audit_asm_loads.py checks the emitted code for compiler accesses to
             // in-flight destinations (tests/test_cpu_oracle.py runs it).
-            MICA_BLOAD((tap + 2) % 3, (g + 2 < nsteps) ? g + 2 : nsteps - 1);
+            MICA_BLOAD((tap + LEAD) % RB, (g + LEAD < nsteps) ? g + LEAD : nsteps - 1);
             if (NJ == 2) asm volatile("s_waitcnt vmcnt(8)" : "+v"(bc[0][0]), "+v"(bc[0][1]), "+v"(bc[NJ - 1][0]), "+v"(bc[NJ - 1][1]));
-            else asm volatile("s_waitcnt vmcnt(4)" : "+v"(bc[0][0]), "+v"(bc[0][1]));
+            else asm volatile("s_waitcnt vmcnt(16)" : "+v"(bc[0][0]), "+v"(bc[0][1]));   // 8 younger steps x 2 loads
             __builtin_amdgcn_sched_barrier(0);
             // One LDS-DMA instruction of the next chunk per tap (DPW = 9 = taps): vmcnt retires in order, so a burst of
             // nine DMAs in front of a fragment wait would stall it for a full HBM round trip; one per tap, issued after
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
     // Drain the (redundant) tail loads and keep every ring register live up to here: a dead asm destination could be
     // re-used by the compiler while its load is still in flight.
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[r][j][0]), "+v"(bq[r][j][1]));
     // ---- output transform through LDS: region [wn][zfrag 4][p 4][row 32][col 32] floats per j -------

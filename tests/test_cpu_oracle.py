@@ -200,7 +200,7 @@ def test_inline_asm_weight_prefetch_is_hazard_free(tmp_path):
                           stderr=subprocess.DEVNULL)
     text = open(asm).read()
     found = 0
-    for variant, keep in (("ILi128ELi2E", 8), ("ILi64ELi2E", 4), ("ILi32ELi1E", 4)):
+    for variant, keep in (("ILi128ELi2E", 8), ("ILi64ELi2E", 16), ("ILi32ELi1E", 16)):
         m = re.search(r"^_ZN4mica16conv_wino_kernel" + variant + r".*?s_endpgm", text, flags=re.S | re.M)
         assert m, variant
         part = str(tmp_path / (variant + ".s"))
