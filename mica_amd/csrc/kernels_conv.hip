@@ -5,6 +5,9 @@
 // 142,158-174,210,212.  Also: weight packing, depthwise 3^3 (model.py:80) and the Cin=1 multi-scale
 // stem (model.py:9-14).
 #include "common.h"
+#include <vector>
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace mica {
@@ -679,6 +682,369 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
     }
 }
 
+// ================================================================================================
+// conv_wino16: the 128-channel variant of conv_wino on the v_mfma_f32_16x16x32_f16 shape, as a PERSISTENT kernel.
+//
+// MFMA shape.  The kernel is power-bound, and on this chip the 16x16x32 shape sustains 1.43x the f16 FLOP/s of 32x32x16 on
+// random operands held in registers (tools/mfma_shape_bench.hip: 1775 vs 1241 TF).  K = 32 per instruction is filled from
+// ONE 16-channel chunk by regrouping the three split products:
+//   X(t)    : A = [a_hi | a_lo] (the four LDS planes are exactly the four k-groups),  B = [b_hi ; b_hi]
+//             = a_hi.b_hi + a_lo.b_hi of tap t
+//   Y(t,t') : A = [a_hi(t) | a_hi(t')],  B = [b_lo(t) ; b_lo(t')]   = the a_hi.b_lo terms of two taps
+// 9 taps = 4 pairs + tap 8 alone (its Y has a zero upper half): 14 instead of 13.5 MFMAs per tile and chunk.
+// A wave owns 128 rows x 64 channels = 8 row fragments (8 pairs x 2 y of one z) x 4 column tiles; a chunk is 14 steps
+// (pair-step, kind Y / X' / X) of 32 MFMAs on 32 distinct accumulators.  A step's four weight fragments are fetched one
+// step ahead by inline-asm loads into two register sets; the A fragments stream through a four-deep register pipeline.
+//
+// Persistence.  Only one workgroup fits a CU (147 KB of LDS), so a workgroup's prologue (first slab, HBM latency), its
+// epilogue and the dispatch gap were all exposed: 30 K of 290 K cycles per 256-channel tile.  Here one workgroup per CU
+// walks its share of the (batch, tile, channel block) items; the slab and weight pipelines run ACROSS items (the last
+// chunk of an item fetches chunk 0 of the next), and the output transform uses only the slab buffer that is idle.
+// Every LDS slot of a slab is rewritten per chunk (DMA, or an explicit zero for positions outside the volume).
+// ================================================================================================
+typedef float floatx4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ constexpr int w16_step_ps(int st) { return st < 12 ? st / 3 : 4; }
+__device__ __forceinline__ constexpr int w16_step_kind(int st) { return st < 12 ? st % 3 : (st - 12) * 2; }   // 0 Y, 1 X' (second tap), 2 X (first tap)
+__device__ __forceinline__ int a_frag_base(int st, int bx, int bya, int byb) {
+    return w16_step_kind(st) == 0 ? (w16_step_ps(st) == 1 ? byb : bya) : bx;
+}
+__device__ __forceinline__ constexpr int a_frag_off(int i) {
+    const int st = i >> 3, f = i & 7;
+    const int tap = 2 * w16_step_ps(st) + (w16_step_kind(st) == 1 ? 1 : 0);
+    return (((f >> 1) + tap / 3) * GeoW::PZ + (tap % 3) * 8 + (f & 1) * 16) * 16;
+}
+// LDS byte offset of the k-th slab DMA instruction of `wave` (wave-uniform)
+__device__ __forceinline__ int w16_slab_loff(int wave, int k) {
+    const int ii = wave * GeoW::DPW + k;
+    const int q = ii / (GeoW::SZ * GeoW::DPZ), rem = ii % (GeoW::SZ * GeoW::DPZ);
+    return (q * GeoW::PLANE + (rem / GeoW::DPZ) * GeoW::PZ + (rem % GeoW::DPZ) * 64) * 16;
+}
+// Tile-independent part of the global BYTE offset (within a 16-channel chunk of the wino operand) this lane fetches with DMA
+// instruction k, relative to the slab origin (z0, y0, i0); the slab row vy of the lane rides in the low three bits
+// (the offset is a multiple of 16).  vz is wave-uniform: w16_slab_vz.
+__device__ __forceinline__ int w16_slab_rel(int wave, int lane, int k, int H, int Wh, int Vh) {
+    const int ii = wave * GeoW::DPW + k;
+    const int q = ii / (GeoW::SZ * GeoW::DPZ), rem = ii % (GeoW::SZ * GeoW::DPZ);
+    const int vz = rem / GeoW::DPZ, part = rem % GeoW::DPZ;
+    const int slot = part * 64 + lane;
+    const int pp = slot / GeoW::PP, r2 = slot - pp * GeoW::PP;
+    const int vy = r2 >> 3, pr = r2 & 7;          // pr == lane & 7 for every k
+    return ((pp * Vh + (vz * H + vy) * Wh + pr) * 32 + q * 8) * 2 + vy;
+}
+__device__ __forceinline__ int w16_slab_vz(int wave, int k) { return ((wave * GeoW::DPW + k) % (GeoW::SZ * GeoW::DPZ)) / GeoW::DPZ; }
+// Chan's pairwise merge of (count, mean, M2)
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float on, float om, float oq) {
+    const float tn = n + on;
+    if (tn > 0.f) {
+        const float dl = om - mean;
+        const float mm = (n > 0.f) ? mean + dl * (on / tn) : om;
+        const float qq = (n > 0.f && on > 0.f) ? m2 + oq + dl * dl * (n * on / tn) : (n > 0.f ? m2 : oq);
+        mean = mm;
+        m2 = qq;
+    }
+    n = tn;
+}
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
+                                                             const float* __restrict__ bias, float out_scale,
+                                                             float* __restrict__ out, Dims d, int cout, int total_chunks,
+                                                             int ntx, int nty, int nnb, int items_per_b, int total_items,
+                                                             float* __restrict__ stats_ws) {
+    using G = GeoW;
+    static_assert(BN == 128, "one variant");
+    constexpr int WNC = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 3, wn = wave >> 2;
+    const int Wh = (d.W + 1) >> 1;
+    const int V = d.D * d.H * d.W, Vh = d.D * d.H * Wh;
+
+    // persistent schedule: workgroup g sits on XCD g & 7 (round-robin dispatch); each XCD takes a contiguous eighth of the
+    // items so that the 32 CUs sharing an L2 work on neighbouring tiles and on the same weights at the same time
+    const int xcd = blockIdx.x & 7, lwg = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int range = (total_items + 7) >> 3;
+    const int it_end = min(total_items, (xcd + 1) * range);
+    int item = xcd * range + lwg;
+    if (item >= it_end) return;
+
+    // A operand addressing: lane = (row r = lane&15 -> pair r&7, y-in-fragment r>>3 ; k-group g = lane>>4)
+    const int lr = lane & 15, lg = lane >> 4;
+    const int rowslot = wp * G::PP + (lr >> 3) * 8 + (lr & 7);
+    const int a_baseX = (lg * G::PLANE + rowslot) * 16;                                   // k-group g reads plane g
+    const int a_baseYa = ((lg & 1) * G::PLANE + rowslot + (lg >= 2 ? 8 : 0)) * 16;        // pairs (t, t+1) with dy+1
+    const int a_baseYb = ((lg & 1) * G::PLANE + rowslot + (lg >= 2 ? G::PZ - 16 : 0)) * 16; // pair (2,3): (dz,2) -> (dz+1,0)
+
+    // packed weights: [nb][chunk][pair-step 5][p 4][unit 8][128 cout][8 halves] - a workgroup's slice is contiguous and
+    // every stride is a compile-time constant; units: 0,1 hi(t) k-half 0,1 | 2,3 hi(t') | 4,5 lo(t) | 6,7 lo(t')
+    constexpr int ustride = BN * 16;                        // bytes per unit
+    constexpr int psstride = 4 * 8 * ustride;               // bytes per pair-step (65,536)
+    constexpr int chstride = 5 * psstride;                  // bytes per chunk
+    const unsigned wlaneX = (unsigned)((lg & 1) * BN + lr) * 16u;
+    const unsigned wlaneY = (unsigned)(lg * BN + lr) * 16u;
+    const int64_t nbstride = (int64_t)total_chunks * chstride;
+    const char* wwave = reinterpret_cast<const char*>(wpk) + wp * 8 * ustride + wn * WNC * 16;
+
+    half8 bq[2][4];
+#define MICA_BLOAD16(set, wbase, stc)                                                                                   \
+    do {                                                                                                                \
+        const int st_ = (stc);                                 /* compile-time after unrolling */                        \
+        const int ps_ = w16_step_ps(st_), kd_ = w16_step_kind(st_);                                                     \
+        const char* pb_ = (wbase) + ps_ * psstride + (kd_ == 0 ? 4 : kd_ == 1 ? 2 : 0) * ustride;                       \
+        const unsigned vo_ = kd_ == 0 ? wlaneY : wlaneX;                                                                \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][0]) : "v"(vo_), "s"(pb_) : "memory");              \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(bq[set][1]) : "v"(vo_), "s"(pb_) : "memory");   \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(bq[set][2]) : "v"(vo_), "s"(pb_) : "memory");   \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:768" : "=v"(bq[set][3]) : "v"(vo_), "s"(pb_) : "memory");   \
+    } while (0)
+    // One slab DMA instruction: issued UNCONDITIONALLY (lanes outside the volume are masked off by hand and write an explicit
+    // zero instead) so that the number of vector-memory operations in flight is known at compile time: the weight waits can
+    // then leave the newest DMA outstanding instead of exposing its HBM latency every step.
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#define MICA_SLAB_DMA(srcbase, bufoff, k, sbase, sy0, sz0, xok)                                                          \
+    do {                                                                                                                \
+        const int lo_ = (bufoff) + w16_slab_loff(wave, k);                                                              \
+        const unsigned la_ = __builtin_amdgcn_readfirstlane(lds0 + lo_);                                                \
+        const bool ok_ = (xok) && (unsigned)((sy0) + (rel[k] & 7)) < (unsigned)d.H &&                                   \
+                         (unsigned)((sz0) + w16_slab_vz(wave, k)) < (unsigned)d.D;                                      \
+        const int go_ = ok_ ? (sbase) + (rel[k] & ~15) : -1;                                                            \
+        unsigned long long sv_;                                                                                         \
+        asm volatile("s_mov_b64 %0, exec\n\tv_cmp_lt_i32 vcc, -1, %1\n\ts_mov_b64 exec, vcc\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" \
+                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                                              \
+                     : "=&s"(sv_) : "v"(go_), "s"(srcbase), "s"(la_) : "memory", "vcc", "m0");                           \
+        if (!ok_) *reinterpret_cast<uint4*>(smem + lo_ + lane * 16) = make_uint4(0, 0, 0, 0);                           \
+    } while (0)
+    // slab origin of a tile: scalar byte offset of (z0, y0, i0) and the per-lane x validity
+#define MICA_TILE_ORIGIN(tile, sbase, sy0, sz0, xok)                                                                    \
+    const int sy0 = ((tile) / ntx % nty) * 4 - 1, sz0 = ((tile) / (ntx * nty)) * 4 - 1;                                 \
+    const int sbase = ((sz0 * d.H + sy0) * Wh + ((tile) % ntx) * 8) * 64;                                               \
+    const bool xok = ((tile) % ntx) * 8 + (lane & 7) < Wh
+
+    int ib = item / items_per_b, inb = (item - ib * items_per_b) % nnb, itile = (item - ib * items_per_b) / nnb;
+    int rel[G::DPW];
+#pragma unroll
+    for (int k = 0; k < G::DPW; ++k) rel[k] = w16_slab_rel(wave, lane, k, d.H, Wh, Vh);
+    const char* witem = wwave + (int64_t)ib * wpk_bstride * 2 + inb * nbstride;
+
+    // prologue of the first item: slab chunk 0 -> buffer 0, weights of step 0
+    MICA_BLOAD16(0, witem, 0);
+    {
+        const _Float16* src0 = chunk_base_wino(s, 0, ib, Vh);
+        MICA_TILE_ORIGIN(itile, fbase, fy0, fz0, fxok);
+#pragma unroll
+        for (int k = 0; k < G::DPW; ++k) MICA_SLAB_DMA(src0, 0, k, fbase, fy0, fz0, fxok);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int par = 0;                                   // slab buffer holding the current chunk
+
+    for (;;) {
+        const int nitem = item + per_xcd;
+        const bool has_next = nitem < it_end;
+        const int ni = has_next ? nitem : item;    // past the end: the pipelines re-fetch this item's first chunk, harmlessly
+        const int nxb = ni / items_per_b, nxnb = (ni - nxb * items_per_b) % nnb, nxtile = (ni - nxb * items_per_b) / nnb;
+        const char* wnitem = wwave + (int64_t)nxb * wpk_bstride * 2 + nxnb * nbstride;
+
+        floatx4v acc[8][4];
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[f][c][i] = 0.f;
+
+        for (int gch = 0; gch < total_chunks; ++gch) {
+            const char* A = smem + par * G::CH_BYTES;
+            const int nxt_off = (par ^ 1) * G::CH_BYTES;
+            const bool last = gch + 1 == total_chunks;
+            const int stile = last ? nxtile : itile;         // the last chunk's DMAs fetch the NEXT item's first slab
+            MICA_TILE_ORIGIN(stile, sbase, sy0, sz0, sxok);
+            const _Float16* nsrc = last ? chunk_base_wino(s, 0, nxb, Vh) : chunk_base_wino(s, gch + 1, ib, Vh);
+            const char* wcur = witem + (int64_t)gch * chstride;
+            const char* wnxt = last ? wnitem : wcur + chstride;
+            // fragment i = step * 8 + f of this chunk: step -> (pair-step, kind) -> tap (dz, dy) and operand base; f -> (z, y pair)
+#define MICA_AFRAG(i) (*reinterpret_cast<const half8*>(A + a_frag_base((i) >> 3, a_baseX, a_baseYa, a_baseYb) + a_frag_off(i)))
+            half8 a0 = MICA_AFRAG(0), a1 = MICA_AFRAG(1), a2 = MICA_AFRAG(2), a3;
+#pragma unroll
+            for (int st = 0; st < 14; ++st) {
+                half8 (&bc)[4] = bq[st & 1];
+                if (st + 1 < 14) MICA_BLOAD16((st + 1) & 1, wcur, st + 1);
+                else MICA_BLOAD16(0, wnxt, 0);
+                // in flight and NEWER than this step's fragments: the four weight loads just issued plus the slab DMA of the
+                // previous step (steps 0..DPW-1 issue one each); loads return in order
+                if (st >= 1 && st <= G::DPW)
+                    asm volatile("s_waitcnt vmcnt(5)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
+                else
+                    asm volatile("s_waitcnt vmcnt(4)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
+                __builtin_amdgcn_sched_barrier(0);
+                if (st < G::DPW) MICA_SLAB_DMA(nsrc, nxt_off, st, sbase, sy0, sz0, sxok);
+                // A fragments stream through a four-deep register pipeline that runs across the steps of a chunk (the
+                // fragment three groups ahead is read while this group's MFMAs issue); the order is pinned per group so the
+                // scheduler cannot pull more LDS reads forward than the register budget (256) allows
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    if (st * 8 + f + 3 < 112) a3 = MICA_AFRAG(st * 8 + f + 3);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)      // asm: ties the accumulator in place (the untied builtin lets the allocator
+                                                     // rotate 128 accumulator registers through the file and spill)
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(a0), "v"(bc[c]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    a0 = a1;
+                    a1 = a2;
+                    a2 = a3;
+                }
+            }
+#undef MICA_AFRAG
+            // the slab DMAs of this chunk are older than the four weight loads still wanted in flight
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __syncthreads();
+            par ^= 1;
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU/LDS readers: the hazard the compiler cannot see through the asm
+
+        // ---- output transform through the idle slab buffer (the other one already holds the next item's first chunk) ----
+        // four passes (32-column half j, wave column group wq): region [z 4][p 4][row 32 = y*8+pair][36 (32 cols, padded)] floats
+        {
+            constexpr int RS = 36, REG = 32 * RS;
+            float* xs = reinterpret_cast<float*>(smem + (par ^ 1) * G::CH_BYTES);
+            const int tx = itile % ntx, ty = (itile / ntx) % nty, tz = itile / (ntx * nty);
+            const int fz = wave & 3, fch = wave >> 2;            // finishing role: z plane, 16-column half
+            const int frow = lane >> 2, fcg = lane & 3;
+            const int P = (items_per_b / nnb) * 4;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int j = pass >> 1, wq = pass & 1;
+                if (wn == wq) {
+                    // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) {
+                        float* dst = xs + ((f >> 1) * 4 + wp) * REG;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int r = lg * 4 + i;                    // row in the 16-row fragment: pair = r&7, y = r>>3
+                                const int r32 = ((f & 1) * 2 + (r >> 3)) * 8 + (r & 7);
+                                dst[r32 * RS + c * 16 + lr] = acc[f][j * 2 + c][i];
+                            }
+                    }
+                }
+                __syncthreads();
+                {
+                    const float* src = xs + (fz * 4) * REG + fch * 16 + fcg * 4;
+                    const int n0 = inb * BN + wq * WNC + j * 32 + fch * 16 + fcg * 4;
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (bias) bv = *reinterpret_cast<const float4*>(bias + n0);
+                    const int gz = tz * 4 + fz;
+                    // statistics: sums of (v - shift) and (v - shift)^2 with ONE shift per channel for the whole wave - the
+                    // tile's first voxel (row 0 is inside the volume whenever this z plane is) - so that the 16 row lanes
+                    // combine by plain adds in a fixed order; (count, mean, M2) are formed once per channel at the end
+                    float sn = 0.f;
+                    float sk[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int r = it * 16 + frow;
+                        const float4 m0 = *reinterpret_cast<const float4*>(src + 0 * REG + r * RS);
+                        const float4 m1 = *reinterpret_cast<const float4*>(src + 1 * REG + r * RS);
+                        const float4 m2 = *reinterpret_cast<const float4*>(src + 2 * REG + r * RS);
+                        const float4 m3 = *reinterpret_cast<const float4*>(src + 3 * REG + r * RS);
+                        const int gx = (tx * 8 + (r & 7)) * 2, gy = ty * 4 + (r >> 3);
+                        float ve[4], vo[4];
+                        ve[0] = (m0.x + m1.x + m2.x) * out_scale + bv.x; vo[0] = (m1.x - m2.x - m3.x) * out_scale + bv.x;
+                        ve[1] = (m0.y + m1.y + m2.y) * out_scale + bv.y; vo[1] = (m1.y - m2.y - m3.y) * out_scale + bv.y;
+                        ve[2] = (m0.z + m1.z + m2.z) * out_scale + bv.z; vo[2] = (m1.z - m2.z - m3.z) * out_scale + bv.z;
+                        ve[3] = (m0.w + m1.w + m2.w) * out_scale + bv.w; vo[3] = (m1.w - m2.w - m3.w) * out_scale + bv.w;
+                        if (it == 0) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) sk[c] = __shfl(ve[c], fcg);      // lane fcg holds row 0 of this channel group
+                        }
+                        const bool in = gy < d.H && gz < d.D && gx < d.W, odd = in && gx + 1 < d.W;
+                        if (in) {
+                            float* o = out + ((int64_t)ib * V + (int64_t)(gz * d.H + gy) * d.W + gx) * cout + n0;
+                            *reinterpret_cast<float4*>(o) = make_float4(ve[0], ve[1], ve[2], ve[3]);
+                            if (odd) *reinterpret_cast<float4*>(o + cout) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+                        }
+                        const float we = in ? 1.f : 0.f, wo = odd ? 1.f : 0.f;
+                        sn += we + wo;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float t = (ve[c] - sk[c]) * we, u = (vo[c] - sk[c]) * wo;
+                            s1[c] += t + u;
+                            s2[c] = fmaf(t, t, fmaf(u, u, s2[c]));
+                        }
+                    }
+                    if (stats_ws) {
+#pragma unroll
+                        for (int off = 4; off < 64; off <<= 1) {
+                            sn += __shfl_xor(sn, off);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                s1[c] += __shfl_xor(s1[c], off);
+                                s2[c] += __shfl_xor(s2[c], off);
+                            }
+                        }
+                        if (frow == 0) {
+                            float* wsp = stats_ws + (((int64_t)ib * P + itile * 4 + fz) * cout + n0) * 3;
+                            const float inv = sn > 0.f ? 1.f / sn : 0.f;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                wsp[c * 3] = sn;
+                                wsp[c * 3 + 1] = sn > 0.f ? sk[c] + s1[c] * inv : 0.f;
+                                wsp[c * 3 + 2] = sn > 0.f ? fmaxf(s2[c] - s1[c] * s1[c] * inv, 0.f) : 0.f;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (!has_next) break;
+        item = nitem;
+        ib = nxb; inb = nxnb; itile = nxtile;
+        witem = wnitem;
+    }
+#undef MICA_BLOAD16
+#undef MICA_SLAB_DMA
+#undef MICA_TILE_ORIGIN
+    // nothing may still be in flight towards this workgroup's registers or LDS when it ends
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]));
+}
+
+static bool wino16_enabled(int cout) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MICA_W16");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1 && cout % 128 == 0;
+}
+
+static int launch_conv_wino16(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
+                              float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
+    int total = 0;
+    for (int i = 0; i < s.n; ++i) total += s.chunks[i];
+    int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / 128;
+    size_t lds = 2 * GeoW::CH_BYTES;
+    static int cus = 0;
+    if (!cus) {
+        (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus < 8) cus = 256;
+        cus &= ~7;
+    }
+    // one persistent workgroup per CU (LDS admits no more), a multiple of eight so that every XCD gets the same number
+    const int items_per_b = ntx * nty * ntz * nnb, total_items = items_per_b * B;
+    const int nwg = total_items >= cus ? cus : ((total_items + 7) / 8) * 8;
+    hipLaunchKernelGGL((conv_wino16_kernel<128>), dim3(nwg), dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout,
+                       total, ntx, nty, nnb, items_per_b, total_items, stats_ws);
+    return ntx * nty * ntz * 4;
+}
+
 template <int BN, int WN>
 static int launch_conv_wino_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
                               float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
@@ -701,6 +1067,7 @@ static int launch_conv_wino_t(const ConvSrcs& s, const _Float16* wpk, int64_t wp
 // f32 [B][P][cout][3] = (count, mean, M2), to be merged by launch_stats_finalize.
 int launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
                      float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
+    if (wino16_enabled(cout)) return launch_conv_wino16(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
     if (cout % 128 == 0) return launch_conv_wino_t<128, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
     if (cout % 64 == 0) return launch_conv_wino_t<64, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
     return launch_conv_wino_t<32, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
@@ -748,7 +1115,55 @@ __global__ void pack_weights_wino_kernel(const float* __restrict__ w, int cout, 
     *reinterpret_cast<half8*>(wpk + (int64_t)b * per_b + e * 8) = o;
 }
 
-int64_t packed_weight_halves_wino(int cout, int total_chunks) { return (int64_t)total_chunks * 9 * 16 * cout * 8; }
+// weights for conv_wino16: [B][nb = Cout/128][chunk][pair-step 5][p 4][unit 8][128][8] halves; unit u: 0,1 = hi of tap t
+// (k-half 0,1), 2,3 = hi of tap t' = t+1, 4,5 = lo of tap t, 6,7 = lo of tap t'; pair-step 4 is tap 8 alone (units 2,3,6,7 zero)
+__global__ void pack_weights_wino16_kernel(const float* __restrict__ w, int cout, int cin, Segs sg, int total_chunks,
+                                           const float* __restrict__ cin_scale, float mul, _Float16* __restrict__ wpk,
+                                           int64_t per_b) {
+    const int b = blockIdx.y;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [nb][chunk][ps][p][unit][n128]
+    int64_t total = (int64_t)total_chunks * 5 * 4 * 8 * cout;
+    if (e >= total) return;
+    int nl = e & 127;
+    int u = (e >> 7) & 7;
+    int pp = (e >> 10) & 3;
+    int ps = (e >> 12) % 5;
+    int gch = (e / (5 << 12)) % total_chunks;
+    int n = (int)(e / ((int64_t)(5 << 12) * total_chunks)) * 128 + nl;
+    const int kind = u >> 2, second = (u >> 1) & 1, kh = u & 1;
+    const int tap = 2 * ps + second;
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int kp = gch * 16 + kh * 8 + j;
+        int ci = -1, accp = 0, accc = 0;
+        for (int si = 0; si < sg.n; ++si) {
+            if (kp >= accp && kp < accp + sg.cp[si]) {
+                int local = kp - accp;
+                if (local < sg.c[si]) ci = accc + local;
+            }
+            accp += sg.cp[si];
+            accc += sg.c[si];
+        }
+        float v = 0.f;
+        if (ci >= 0 && tap < 9) {
+            const float* g = w + ((int64_t)n * cin + ci) * 27 + tap * 3;
+            float g0 = g[0], g1 = g[1], g2 = g[2];
+            float uu = pp == 0 ? g0 : pp == 1 ? 0.5f * (g0 + g1 + g2) : pp == 2 ? 0.5f * (g0 - g1 + g2) : g2;
+            v = uu * mul;
+            if (cin_scale) v *= cin_scale[(int64_t)b * cin + ci];
+        }
+        _Float16 hi = (_Float16)v;
+        _Float16 lo = (_Float16)(v - (float)hi);
+        o[j] = kind ? lo : hi;
+    }
+    *reinterpret_cast<half8*>(wpk + (int64_t)b * per_b + e * 8) = o;
+}
+
+int64_t packed_weight_halves_wino(int cout, int total_chunks) {
+    if (wino16_enabled(cout)) return (int64_t)total_chunks * 5 * 32 * cout * 8;
+    return (int64_t)total_chunks * 9 * 16 * cout * 8;
+}
 
 void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_seg_c, const int* h_seg_cp, int nseg,
                               const float* cin_scale, int B, float cout_scale, float wscale, _Float16* wpk, hipStream_t st) {
@@ -759,6 +1174,13 @@ void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_se
         sg.c[i] = h_seg_c[i];
         sg.cp[i] = h_seg_cp[i];
         total_chunks += h_seg_cp[i] / 16;
+    }
+    if (wino16_enabled(cout)) {
+        int64_t total16 = (int64_t)total_chunks * 5 * 32 * cout;
+        dim3 grid16((unsigned)((total16 + 255) / 256), B);
+        hipLaunchKernelGGL(pack_weights_wino16_kernel, grid16, dim3(256), 0, st, w, cout, cin, sg, total_chunks, cin_scale,
+                           cout_scale * wscale, wpk, packed_weight_halves_wino(cout, total_chunks));
+        return;
     }
     int64_t total = (int64_t)total_chunks * 9 * 16 * cout;
     dim3 grid((unsigned)((total + 255) / 256), B);

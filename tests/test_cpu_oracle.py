@@ -210,6 +210,18 @@ def test_inline_asm_weight_prefetch_is_hazard_free(tmp_path):
         assert m.group(0).count("global_load_dwordx4") >= 18 and ".vgpr_spill_count" not in m.group(0)
         found += 1
     assert found == 3
+    # the persistent 16x16x32 variant: same audit with its LDS-DMA instructions occupying queue slots; per chunk 9 waits that
+    # leave the previous step's DMA in flight (vmcnt(5)), 5 + 1 plain ones, and exactly one copy of the 448-MFMA chunk body
+    m = re.search(r"^_ZN4mica18conv_wino16_kernelILi128E.*?s_endpgm", text, flags=re.S | re.M)
+    assert m
+    part = str(tmp_path / "wino16.s")
+    open(part, "w").write(m.group(0))
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), part], text=True)
+    assert "violations: 0" in out, out[-2000:]
+    body = m.group(0)
+    assert body.count("v_mfma_f32_16x16x32_f16") == 448 and body.count("s_waitcnt vmcnt(5)") == 9
+    assert body.count("s_waitcnt vmcnt(4)") == 6 and body.count("global_load_lds_dwordx4") == 18
+    assert "scratch_" not in body
     # no kernel of the file spills (a spilled asm destination would be reloaded/stored around in-flight loads)
     spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
     assert spills and max(spills) == 0, spills

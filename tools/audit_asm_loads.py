@@ -1,5 +1,5 @@
 """Audit a hipcc .s for compiler accesses to the destination registers of hand-waited inline-asm loads
-(development aid for conv_wino_kernel's weight prefetch): between an asm `global_load_dwordx4` and the
+(development aid for the weight prefetch of conv_wino_kernel / conv_wino16_kernel): between an asm `global_load_dwordx4` and the
 hand-placed `s_waitcnt vmcnt(N)` that retires it, no other instruction may read or write its destination."""
 import re, sys
 lines = open(sys.argv[1]).read().split("\n")
@@ -18,6 +18,8 @@ for i, l in enumerate(lines):
     if t.startswith(";;#ASMSTART"): in_asm = True; continue
     if t.startswith(";;#ASMEND"): in_asm = False; continue
     if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"): continue
+    if in_asm and t.startswith("global_load_lds_dwordx4"):
+        inflight.append((-1, -1, i + 1)); continue          # an LDS-DMA occupies a slot of the in-order queue, no register
     if in_asm and t.startswith("global_load_dwordx4"):
         r = regs(t.split(",")[0])[0]
         inflight.append((r[0], r[1], i + 1)); continue
