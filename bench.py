@@ -145,18 +145,18 @@ def main():
         dms, dl, dbytes = eng.profile(1)
         eng.set_profiling(False)
         traffic = {}
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")     # re-collected whenever the conv kernels change
         if os.path.exists(tp) and B == 8 and n == 256 and not args.no_af:      # measured for exactly this workload
             traffic = json.load(open(tp)).get("kernels", {})
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_wino_kernel + conv2_kernel (dense 3x3x3 via Winograd F(2,3)-x, 1x1x1; split-f16 x3 MFMA)",
+        roof = {"bound": "mfma", "kernel": "conv_wino16_kernel (+ conv_wino_kernel for Cout 32, conv2_kernel for 1x1x1): dense 3x3x3 via Winograd F(2,3)-x, split-f16 x3 MFMA",
                 "achieved": ach, "peak": PEAK_SPLIT_TF, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TF,
-                "traffic": traffic.get("conv_wino_kernel", {}).get("hbm_bytes"),
+                "traffic": traffic.get("conv_wino16_kernel", traffic.get("conv_wino_kernel", {})).get("hbm_bytes"),
                 "launches_per_batch": launches, "avg_launch_ms": ms / max(launches, 1),
                 "algorithmic_gflop_per_launch_avg": flops / max(launches, 1) / 1e9,
                 "note": "achieved = algorithmic direct-conv FLOPs (2*k^3*Cin*Cout*V, unpadded) / HIP-event time of the conv launches; "
                         "peak = f16 dense MFMA 2500 TF / 3 MFMAs per f32-grade product; Winograd executes 1.5x fewer MFMAs than the "
-                        "algorithmic count; traffic = PMC HBM bytes per conv_wino launch of `python bench.py` defaults (batch 8; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections, profiles/r01_pmc_traffic.json); null for other batch sizes"}
+                        "algorithmic count; traffic = PMC HBM bytes per conv_wino16 launch of `python bench.py` defaults (batch 8; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections, profiles/r01_pmc_traffic.json); null for other batch sizes"}
         dach = dbytes / (dms * 1e-3) / 1e9
         hbm = {"bound": "hbm", "kernel": "depthwise_kernel (Conv3d groups=C, 3x3x3, IN+ReLU+SE gate fused on load, IN stats fused)",
                "achieved": dach, "peak": 8000.0, "unit": "GB/s", "frac": dach / 8000.0,

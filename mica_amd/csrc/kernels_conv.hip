@@ -703,17 +703,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
 // Every LDS slot of a slab is rewritten per chunk (DMA, or an explicit zero for positions outside the volume).
 // ================================================================================================
 typedef float floatx4v __attribute__((ext_vector_type(4)));
+#ifndef MICA_BLOCKED_WALK
+#define MICA_BLOCKED_WALK 1
+#endif
+
 
 __device__ __forceinline__ constexpr int w16_step_ps(int st) { return st < 12 ? st / 3 : 4; }
 __device__ __forceinline__ constexpr int w16_step_kind(int st) { return st < 12 ? st % 3 : (st - 12) * 2; }   // 0 Y, 1 X' (second tap), 2 X (first tap)
-__device__ __forceinline__ int a_frag_base(int st, int bx, int bya, int byb) {
-    return w16_step_kind(st) == 0 ? (w16_step_ps(st) == 1 ? byb : bya) : bx;
-}
-__device__ __forceinline__ constexpr int a_frag_off(int i) {
-    const int st = i >> 3, f = i & 7;
-    const int tap = 2 * w16_step_ps(st) + (w16_step_kind(st) == 1 ? 1 : 0);
-    return (((f >> 1) + tap / 3) * GeoW::PZ + (tap % 3) * 8 + (f & 1) * 16) * 16;
-}
 // LDS byte offset of the k-th slab DMA instruction of `wave` (wave-uniform)
 __device__ __forceinline__ int w16_slab_loff(int wave, int k) {
     const int ii = wave * GeoW::DPW + k;
@@ -753,7 +749,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                                                              int ntx, int nty, int nnb, int items_per_b, int total_items,
                                                              float* __restrict__ stats_ws) {
     using G = GeoW;
-    static_assert(BN == 128, "one variant");
+    static_assert(BN == 128 || BN == 64, "two variants");
+    // BN = 128: the two wave groups (wn) own 64 output channels each and walk all 14 steps of a chunk.
+    // BN = 64 : both groups own the same 64 channels and SPLIT THE TAPS, 7 steps each (group 0: taps 0..4 less the X terms of
+    //           tap 4/5, group 1: the rest); the per-wave tile, operand reuse and weight traffic per MFMA stay those of the
+    //           128 variant, and the two partial accumulators are added through LDS before the output transform.
+    constexpr bool SPLIT = BN == 64;
+    constexpr int NS = SPLIT ? 7 : 14;              // steps per wave and chunk
     constexpr int WNC = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -771,30 +773,37 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
     int item = xcd * range + lwg;
     if (item >= it_end) return;
 
-    // A operand addressing: lane = (row r = lane&15 -> pair r&7, y-in-fragment r>>3 ; k-group g = lane>>4)
+    // A operand addressing: lane = (row r = lane&15 -> pair r&7, y-in-fragment r>>3 ; k-group g = lane>>4).
+    //   X steps : k-group g reads LDS plane g                       = plane (g&1) + (g>>1) * 2 planes
+    //   Y steps : k-groups 0,1 read hi planes of tap t, 2,3 of t'   = plane (g&1) + (g>>1) * (tap delta: one y row, or for
+    //             the pair (2,3) one z plane less two y rows)
+    // so every step is "common lane address + (g>>1 ? step delta : 0) + step tap offset" with per-step SCALARS - which lets
+    // the two wave groups of the BN = 64 variant run the same instruction stream on different taps.
     const int lr = lane & 15, lg = lane >> 4;
-    const int rowslot = wp * G::PP + (lr >> 3) * 8 + (lr & 7);
-    const int a_baseX = (lg * G::PLANE + rowslot) * 16;                                   // k-group g reads plane g
-    const int a_baseYa = ((lg & 1) * G::PLANE + rowslot + (lg >= 2 ? 8 : 0)) * 16;        // pairs (t, t+1) with dy+1
-    const int a_baseYb = ((lg & 1) * G::PLANE + rowslot + (lg >= 2 ? G::PZ - 16 : 0)) * 16; // pair (2,3): (dz,2) -> (dz+1,0)
+    const int himask = (lg >> 1) ? -1 : 0;
+    const int a_common = ((lg & 1) * G::PLANE + wp * G::PP + (lr >> 3) * 8 + (lr & 7)) * 16;
 
     // packed weights: [nb][chunk][pair-step 5][p 4][unit 8][128 cout][8 halves] - a workgroup's slice is contiguous and
     // every stride is a compile-time constant; units: 0,1 hi(t) k-half 0,1 | 2,3 hi(t') | 4,5 lo(t) | 6,7 lo(t')
     constexpr int ustride = BN * 16;                        // bytes per unit
     constexpr int psstride = 4 * 8 * ustride;               // bytes per pair-step (65,536)
     constexpr int chstride = 5 * psstride;                  // bytes per chunk
-    const unsigned wlaneX = (unsigned)((lg & 1) * BN + lr) * 16u;
-    const unsigned wlaneY = (unsigned)(lg * BN + lr) * 16u;
+    const unsigned w_common = (unsigned)((lg & 1) * BN + lr) * 16u;     // X steps: units (g&1); Y steps: + (g>>1) * 2 units
     const int64_t nbstride = (int64_t)total_chunks * chstride;
-    const char* wwave = reinterpret_cast<const char*>(wpk) + wp * 8 * ustride + wn * WNC * 16;
+    const char* wwave = reinterpret_cast<const char*>(wpk) + wp * 8 * ustride + (SPLIT ? 0 : wn * WNC * 16);
 
-    half8 bq[2][4];
-#define MICA_BLOAD16(set, wbase, stc)                                                                                   \
+    half8 bq[3][4];          // weight fragment sets; the third only when NS is odd (see W16_SET)
+    // step parameters: global step st (0..13) -> scalars; a wave's local step ls is global step ls (+ 7 for group 1 of BN = 64)
+#define W16_TAP(st) (2 * w16_step_ps(st) + (w16_step_kind(st) == 1 ? 1 : 0))
+#define W16_AOFF(st) (((W16_TAP(st) / 3) * G::PZ + (W16_TAP(st) % 3) * 8) * 16)
+#define W16_ADELTA(st) (w16_step_kind(st) != 0 ? 2 * G::PLANE * 16 : (w16_step_ps(st) == 1 ? (G::PZ - 16) * 16 : 8 * 16))
+#define W16_WOFF(st) (w16_step_ps(st) * psstride + (w16_step_kind(st) == 0 ? 4 : w16_step_kind(st) == 1 ? 2 : 0) * ustride)
+#define W16_WDELTA(st) (w16_step_kind(st) == 0 ? 2 * BN * 16 : 0)
+#define W16_SEL(ls, M) ((SPLIT && wn == 1) ? M((ls) + 7) : M(ls))
+#define MICA_BLOAD16(set, wbase, ls)                                                                                    \
     do {                                                                                                                \
-        const int st_ = (stc);                                 /* compile-time after unrolling */                        \
-        const int ps_ = w16_step_ps(st_), kd_ = w16_step_kind(st_);                                                     \
-        const char* pb_ = (wbase) + ps_ * psstride + (kd_ == 0 ? 4 : kd_ == 1 ? 2 : 0) * ustride;                       \
-        const unsigned vo_ = kd_ == 0 ? wlaneY : wlaneX;                                                                \
+        const char* pb_ = (wbase) + W16_SEL(ls, W16_WOFF);                                                              \
+        const unsigned vo_ = w_common + (unsigned)(W16_SEL(ls, W16_WDELTA) & himask);                                   \
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][0]) : "v"(vo_), "s"(pb_) : "memory");              \
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(bq[set][1]) : "v"(vo_), "s"(pb_) : "memory");   \
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(bq[set][2]) : "v"(vo_), "s"(pb_) : "memory");   \
@@ -804,50 +813,87 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
     // zero instead) so that the number of vector-memory operations in flight is known at compile time: the weight waits can
     // then leave the newest DMA outstanding instead of exposing its HBM latency every step.
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-#define MICA_SLAB_DMA(srcbase, bufoff, k, sbase, sy0, sz0, xok)                                                          \
+#define MICA_SLAB_DMA(srcbase, bufoff, k, org)                                                                          \
     do {                                                                                                                \
         const int lo_ = (bufoff) + w16_slab_loff(wave, k);                                                              \
         const unsigned la_ = __builtin_amdgcn_readfirstlane(lds0 + lo_);                                                \
-        const bool ok_ = (xok) && (unsigned)((sy0) + (rel[k] & 7)) < (unsigned)d.H &&                                   \
-                         (unsigned)((sz0) + w16_slab_vz(wave, k)) < (unsigned)d.D;                                      \
-        const int go_ = ok_ ? (sbase) + (rel[k] & ~15) : -1;                                                            \
+        const bool ok_ = (org).i0 + (lane & 7) < Wh && (unsigned)((org).y0 + (rel[k] & 7)) < (unsigned)d.H &&           \
+                         (unsigned)((org).z0 + w16_slab_vz(wave, k)) < (unsigned)d.D;                                   \
+        const int go_ = ok_ ? (org).base + (rel[k] & ~15) : -1;                                                         \
         unsigned long long sv_;                                                                                         \
         asm volatile("s_mov_b64 %0, exec\n\tv_cmp_lt_i32 vcc, -1, %1\n\ts_mov_b64 exec, vcc\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" \
                      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                                              \
                      : "=&s"(sv_) : "v"(go_), "s"(srcbase), "s"(la_) : "memory", "vcc", "m0");                           \
         if (!ok_) *reinterpret_cast<uint4*>(smem + lo_ + lane * 16) = make_uint4(0, 0, 0, 0);                           \
     } while (0)
-    // slab origin of a tile: scalar byte offset of (z0, y0, i0) and the per-lane x validity
-#define MICA_TILE_ORIGIN(tile, sbase, sy0, sz0, xok)                                                                    \
-    const int sy0 = ((tile) / ntx % nty) * 4 - 1, sz0 = ((tile) / (ntx * nty)) * 4 - 1;                                 \
-    const int sbase = ((sz0 * d.H + sy0) * Wh + ((tile) % ntx) * 8) * 64;                                               \
-    const bool xok = ((tile) % ntx) * 8 + (lane & 7) < Wh
 
-    int ib = item / items_per_b, inb = (item - ib * items_per_b) % nnb, itile = (item - ib * items_per_b) / nnb;
+    // Everything per item is scalar and is worked out ONCE per item, one item ahead (during the previous item's epilogue):
+    // decoding an item costs integer divisions and kernel-argument loads that must not sit between a chunk's barrier and its
+    // first MFMA.
+    struct Item {
+        int b, nb, tile;
+        int i0, y0, z0, base;          // slab origin: first x pair, y, z (halo included) and its byte offset in a chunk
+        const char* w;                 // this wave's weights of chunk 0
+        const _Float16* src0;          // chunk 0 of the operand
+    };
+    auto decode = [&](int it) {
+        Item r;
+        r.b = it / items_per_b;
+        const int id = it - r.b * items_per_b;
+        r.nb = id % nnb;
+        // walk order of the tiles: the 32 workgroups of an XCD work on 32 consecutive items at a time, and what neighbouring
+        // tiles share is their y and z halo (none in x) - so consecutive items form compact (8 y x 4 z) blocks of tiles whose
+        // halos the XCD's L2 serves, rather than x-major rows (1.2x instead of 1.6x the ideal slab traffic at Cout <= 128)
+        const int seq = id / nnb;
+        int tx, ty, tz;
+        if (MICA_BLOCKED_WALK && ((nty & 7) | (((d.D + 3) >> 2) & 3)) == 0) {
+            const int inb = seq & 31, blk = seq >> 5, nby = nty >> 3;
+            tx = blk % ntx;
+            ty = (blk / ntx % nby) * 8 + (inb & 7);
+            tz = (blk / (ntx * nby)) * 4 + (inb >> 3);
+        } else {
+            tx = seq % ntx;
+            ty = seq / ntx % nty;
+            tz = seq / (ntx * nty);
+        }
+        r.tile = (tz * nty + ty) * ntx + tx;
+        r.i0 = tx * 8;
+        r.y0 = ty * 4 - 1;
+        r.z0 = tz * 4 - 1;
+        r.base = ((r.z0 * d.H + r.y0) * Wh + r.i0) * 64;
+        r.w = wwave + (int64_t)r.b * wpk_bstride * 2 + r.nb * nbstride;
+        r.src0 = chunk_base_wino(s, 0, r.b, Vh);
+        return r;
+    };
+    const int64_t chunk_halves = (int64_t)Vh * 128;
+
+    Item cur = decode(item);
+    int nitem = item + per_xcd;
+    Item nxt = decode(nitem < it_end ? nitem : item);     // past the end: the pipelines re-fetch this item's first chunk, harmlessly
     int rel[G::DPW];
 #pragma unroll
     for (int k = 0; k < G::DPW; ++k) rel[k] = w16_slab_rel(wave, lane, k, d.H, Wh, Vh);
-    const char* witem = wwave + (int64_t)ib * wpk_bstride * 2 + inb * nbstride;
 
-    // prologue of the first item: slab chunk 0 -> buffer 0, weights of step 0
-    MICA_BLOAD16(0, witem, 0);
-    {
-        const _Float16* src0 = chunk_base_wino(s, 0, ib, Vh);
-        MICA_TILE_ORIGIN(itile, fbase, fy0, fz0, fxok);
+    // step ls of a wave's NS uses set W16_SET(ls): alternating, except that with NS odd the first step of a chunk has a set
+    // of its own (its fragments are fetched during the last step of the previous chunk, which uses set 0 itself)
+#define W16_SET(ls) ((SPLIT && (ls) == 0) ? 2 : ((ls) & 1))
+    // slab DMA instructions issued in step ls (9 per wave and chunk, none in the last step so that the chunk-end wait can
+    // leave exactly the next chunk's weight loads in flight)
+#define W16_NDMA(ls) (SPLIT ? ((ls) < 3 ? 2 : (ls) < 6 ? 1 : 0) : ((ls) < G::DPW ? 1 : 0))
+    // steps in which group 0 holds the high priority: 9 of 14 (0,1,3,4,6,7,9,10,12) resp. 4 of 7 (0,1,3,4); measured flat
+    // between 7 and 10 of 14
+#define W16_XHI(ls) (((SPLIT ? 0x1B : 0x16DB) >> (ls)) & 1)
+#define W16_DMA0(ls) (SPLIT ? ((ls) < 3 ? 2 * (ls) : (ls) + 3) : (ls))
+    // prologue of the first item: slab chunk 0 -> buffer 0, weights of the wave's first step
+    MICA_BLOAD16(W16_SET(0), cur.w, 0);
 #pragma unroll
-        for (int k = 0; k < G::DPW; ++k) MICA_SLAB_DMA(src0, 0, k, fbase, fy0, fz0, fxok);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    for (int k = 0; k < G::DPW; ++k) MICA_SLAB_DMA(cur.src0, 0, k, cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int par = 0;                                   // slab buffer holding the current chunk
 
     for (;;) {
-        const int nitem = item + per_xcd;
         const bool has_next = nitem < it_end;
-        const int ni = has_next ? nitem : item;    // past the end: the pipelines re-fetch this item's first chunk, harmlessly
-        const int nxb = ni / items_per_b, nxnb = (ni - nxb * items_per_b) % nnb, nxtile = (ni - nxb * items_per_b) / nnb;
-        const char* wnitem = wwave + (int64_t)nxb * wpk_bstride * 2 + nxnb * nbstride;
-
         floatx4v acc[8][4];
 #pragma unroll
         for (int f = 0; f < 8; ++f)
@@ -856,97 +902,155 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[f][c][i] = 0.f;
 
+        // running pointer to the operand chunk after the current one (the sources of a virtual concat are walked in order)
+        const _Float16* run = cur.src0;
+        int si = 0, left = s.chunks[0];
+        const char* wcur = cur.w;
         for (int gch = 0; gch < total_chunks; ++gch) {
             const char* A = smem + par * G::CH_BYTES;
             const int nxt_off = (par ^ 1) * G::CH_BYTES;
             const bool last = gch + 1 == total_chunks;
-            const int stile = last ? nxtile : itile;         // the last chunk's DMAs fetch the NEXT item's first slab
-            MICA_TILE_ORIGIN(stile, sbase, sy0, sz0, sxok);
-            const _Float16* nsrc = last ? chunk_base_wino(s, 0, nxb, Vh) : chunk_base_wino(s, gch + 1, ib, Vh);
-            const char* wcur = witem + (int64_t)gch * chstride;
-            const char* wnxt = last ? wnitem : wcur + chstride;
-            // fragment i = step * 8 + f of this chunk: step -> (pair-step, kind) -> tap (dz, dy) and operand base; f -> (z, y pair)
-#define MICA_AFRAG(i) (*reinterpret_cast<const half8*>(A + a_frag_base((i) >> 3, a_baseX, a_baseYa, a_baseYb) + a_frag_off(i)))
-            half8 a0 = MICA_AFRAG(0), a1 = MICA_AFRAG(1), a2 = MICA_AFRAG(2), a3;
+            if (!last) {
+                if (--left == 0) {
+                    ++si;
+                    left = s.chunks[si];
+                    run = s.p[si] + ((int64_t)cur.b * s.chunks_total[si] + s.chunk_off[si]) * chunk_halves;
+                } else {
+                    run += chunk_halves;
+                }
+            }
+            const _Float16* nsrc = last ? nxt.src0 : run;        // the last chunk's DMAs fetch the NEXT item's first slab
+            Item org = cur;
+            if (last) org = nxt;
+            const char* wnxt = last ? nxt.w : wcur + chstride;
+            // The NS steps of this wave in this chunk.  Per step: fetch the next step's weight fragments, wait for this
+            // step's (in flight and NEWER: the four loads just issued plus the slab DMAs of the previous step; loads return in
+            // order), issue this step's slab DMAs, then 8 groups (row fragment f = (z, y pair)) of 4 MFMAs.  The A fragments
+            // stream through a four-deep register pipeline that runs across the steps (the fragment three groups ahead is read
+            // while this group's MFMAs issue); the order is pinned per group so the scheduler cannot pull more LDS reads forward
+            // than the register budget (256) allows.  The MFMA is asm: that ties the accumulator in place (the untied builtin
+            // lets the allocator rotate 128 accumulator registers through the file and spill).
+#define W16_ABASE(ls) (A + a_common + (W16_SEL(ls, W16_ADELTA) & himask) + W16_SEL(ls, W16_AOFF))
+#define W16_AFRAG(base, f) (*reinterpret_cast<const half8*>((base) + ((((f) >> 1) * G::PZ + ((f) & 1) * 16) * 16)))
+            const char* ab_cur = W16_ABASE(0);
+            half8 a0 = W16_AFRAG(ab_cur, 0), a1 = W16_AFRAG(ab_cur, 1), a2 = W16_AFRAG(ab_cur, 2), a3;
 #pragma unroll
-            for (int st = 0; st < 14; ++st) {
-                half8 (&bc)[4] = bq[st & 1];
-                if (st + 1 < 14) MICA_BLOAD16((st + 1) & 1, wcur, st + 1);
-                else MICA_BLOAD16(0, wnxt, 0);
-                // in flight and NEWER than this step's fragments: the four weight loads just issued plus the slab DMA of the
-                // previous step (steps 0..DPW-1 issue one each); loads return in order
-                if (st >= 1 && st <= G::DPW)
-                    asm volatile("s_waitcnt vmcnt(5)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
-                else
-                    asm volatile("s_waitcnt vmcnt(4)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
+            for (int ls = 0; ls < NS; ++ls) {
+                half8 (&bc)[4] = bq[W16_SET(ls)];
+                if (ls + 1 < NS) MICA_BLOAD16(W16_SET(ls + 1), wcur, ls + 1);
+                else MICA_BLOAD16(W16_SET(0), wnxt, 0);
+                const int newer = 4 + (ls >= 1 ? W16_NDMA(ls - 1) : 0);
+                if (newer == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
+                else if (newer == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
+                else asm volatile("s_waitcnt vmcnt(6)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
+                static_assert(W16_NDMA(0) <= 2, "wait immediates above: 4, 5 or 6 newer operations");
                 __builtin_amdgcn_sched_barrier(0);
-                if (st < G::DPW) MICA_SLAB_DMA(nsrc, nxt_off, st, sbase, sy0, sz0, sxok);
-                // A fragments stream through a four-deep register pipeline that runs across the steps of a chunk (the
-                // fragment three groups ahead is read while this group's MFMAs issue); the order is pinned per group so the
-                // scheduler cannot pull more LDS reads forward than the register budget (256) allows
+#pragma unroll
+                for (int q = 0; q < W16_NDMA(ls); ++q) MICA_SLAB_DMA(nsrc, nxt_off, W16_DMA0(ls) + q, org);
+                const char* ab_nxt = ab_cur;
+                if (ls + 1 < NS) ab_nxt = W16_ABASE(ls + 1);
 #pragma unroll
                 for (int f = 0; f < 8; ++f) {
-                    if (st * 8 + f + 3 < 112) a3 = MICA_AFRAG(st * 8 + f + 3);
+                    // Two waves share a SIMD (wave w and w + 4, i.e. the two groups).  The MFMA arbiter is strictly "highest
+                    // priority, then oldest": left alone, group 0 runs at its solo speed (about 60 % of the pipe, the rest
+                    // are its own waits), group 1 only fills the gaps and then finishes ALONE at that same 60 %.  Group 1
+                    // therefore holds priority 1 and group 0 alternates between 2 and 0 so that each is the gap filler for a
+                    // share of the chunk and both reach the chunk barrier together with the pipe contended throughout.
+                    if (f == 0) {
+                        if (wn == 0) {
+                            if (W16_XHI(ls)) asm volatile("s_setprio 2"); else asm volatile("s_setprio 0");
+                        } else if (ls == 0) {
+                            asm volatile("s_setprio 1");
+                        }
+                    }
+                    if (f + 3 < 8) a3 = W16_AFRAG(ab_cur, f + 3);
+                    else if (ls + 1 < NS) a3 = W16_AFRAG(ab_nxt, f + 3 - 8);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)      // asm: ties the accumulator in place (the untied builtin lets the allocator
-                                                     // rotate 128 accumulator registers through the file and spill)
+                    for (int c = 0; c < 4; ++c)
                         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(a0), "v"(bc[c]));
                     __builtin_amdgcn_sched_barrier(0);
                     a0 = a1;
                     a1 = a2;
                     a2 = a3;
                 }
+                ab_cur = ab_nxt;
             }
-#undef MICA_AFRAG
+#undef W16_ABASE
+#undef W16_AFRAG
             // the slab DMAs of this chunk are older than the four weight loads still wanted in flight
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __syncthreads();
             par ^= 1;
+            wcur = wnxt;
         }
+        asm volatile("s_setprio 0");
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU/LDS readers: the hazard the compiler cannot see through the asm
 
         // ---- output transform through the idle slab buffer (the other one already holds the next item's first chunk) ----
-        // four passes (32-column half j, wave column group wq): region [z 4][p 4][row 32 = y*8+pair][36 (32 cols, padded)] floats
+        // four passes of CP columns; transform region T = [z 4][p 4][row 32 = y*8+pair][CP + 4 (padded)] floats.
+        //   BN = 128: pass = (32-column half j, wave group wq): that group writes its accumulators to T.
+        //   BN = 64 : pass = column tile; group 1 first hands its partial sums to group 0 through a 32 KB exchange area in
+        //             front of T ([p 4][f 8][lane 64] float4), group 0 adds them and writes T.
+        // Then all eight waves finish: wave -> (z plane, half of the CP columns), lane -> (row, 4-channel group).
         {
-            constexpr int RS = 36, REG = 32 * RS;
-            float* xs = reinterpret_cast<float*>(smem + (par ^ 1) * G::CH_BYTES);
+            constexpr int CP = SPLIT ? 16 : 32, RS = CP + 4, REG = 32 * RS;
+            constexpr int CG = CP / 8, RPI = 64 / CG, ITS = 32 / RPI;        // 4-channel groups per row, rows per iteration
+            char* ebuf = smem + (par ^ 1) * G::CH_BYTES;
+            float4* xp = reinterpret_cast<float4*>(ebuf);                    // BN = 64: partial-sum exchange
+            float* xs = reinterpret_cast<float*>(ebuf + (SPLIT ? 32768 : 0));
+            static_assert((SPLIT ? 32768 : 0) + 16 * REG * 4 <= G::CH_BYTES, "epilogue fits one slab buffer");
+            const int ib = cur.b, inb = cur.nb, itile = cur.tile;
             const int tx = itile % ntx, ty = (itile / ntx) % nty, tz = itile / (ntx * nty);
-            const int fz = wave & 3, fch = wave >> 2;            // finishing role: z plane, 16-column half
-            const int frow = lane >> 2, fcg = lane & 3;
+            const int nnitem = nitem + per_xcd;
+            const Item nn = decode(nnitem < it_end ? nnitem : (has_next ? nitem : item));     // the item after next, for the next round
+            const int fz = wave & 3, fch = wave >> 2;            // finishing role: z plane, column half
+            const int frow = lane / CG, fcg = lane % CG;
             const int P = (items_per_b / nnb) * 4;
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
-                const int j = pass >> 1, wq = pass & 1;
+                const int c0 = SPLIT ? pass : (pass >> 1) * 2;       // first column tile of the pass
+                const int wq = SPLIT ? 0 : (pass & 1);               // the group that writes T
+                if (SPLIT) {
+                    if (wn == 1) {
+#pragma unroll
+                        for (int f = 0; f < 8; ++f)
+                            xp[(wp * 8 + f) * 64 + lane] = make_float4(acc[f][c0][0], acc[f][c0][1], acc[f][c0][2], acc[f][c0][3]);
+                    }
+                    __syncthreads();
+                }
                 if (wn == wq) {
                     // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
                     for (int f = 0; f < 8; ++f) {
                         float* dst = xs + ((f >> 1) * 4 + wp) * REG;
+                        float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (SPLIT) add = xp[(wp * 8 + f) * 64 + lane];
+                        const float addv[4] = {add.x, add.y, add.z, add.w};
 #pragma unroll
-                        for (int c = 0; c < 2; ++c)
+                        for (int c = 0; c < CP / 16; ++c)
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const int r = lg * 4 + i;                    // row in the 16-row fragment: pair = r&7, y = r>>3
                                 const int r32 = ((f & 1) * 2 + (r >> 3)) * 8 + (r & 7);
-                                dst[r32 * RS + c * 16 + lr] = acc[f][j * 2 + c][i];
+                                dst[r32 * RS + c * 16 + lr] = acc[f][c0 + c][i] + addv[i];
                             }
                     }
                 }
                 __syncthreads();
                 {
-                    const float* src = xs + (fz * 4) * REG + fch * 16 + fcg * 4;
-                    const int n0 = inb * BN + wq * WNC + j * 32 + fch * 16 + fcg * 4;
+                    const float* src = xs + (fz * 4) * REG + fch * (CP / 2) + fcg * 4;
+                    const int n0 = inb * BN + (SPLIT ? pass * 16 : wq * WNC + (pass >> 1) * 32) + fch * (CP / 2) + fcg * 4;
                     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (bias) bv = *reinterpret_cast<const float4*>(bias + n0);
                     const int gz = tz * 4 + fz;
                     // statistics: sums of (v - shift) and (v - shift)^2 with ONE shift per channel for the whole wave - the
-                    // tile's first voxel (row 0 is inside the volume whenever this z plane is) - so that the 16 row lanes
+                    // tile's first voxel (row 0 is inside the volume whenever this z plane is) - so that the row lanes
                     // combine by plain adds in a fixed order; (count, mean, M2) are formed once per channel at the end
                     float sn = 0.f;
                     float sk[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const int r = it * 16 + frow;
+                    for (int it = 0; it < ITS; ++it) {
+                        const int r = it * RPI + frow;
                         const float4 m0 = *reinterpret_cast<const float4*>(src + 0 * REG + r * RS);
                         const float4 m1 = *reinterpret_cast<const float4*>(src + 1 * REG + r * RS);
                         const float4 m2 = *reinterpret_cast<const float4*>(src + 2 * REG + r * RS);
@@ -978,7 +1082,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                     }
                     if (stats_ws) {
 #pragma unroll
-                        for (int off = 4; off < 64; off <<= 1) {
+                        for (int off = CG; off < 64; off <<= 1) {
                             sn += __shfl_xor(sn, off);
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
@@ -998,39 +1102,56 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                         }
                     }
                 }
-                __syncthreads();
+                if (!SPLIT) __syncthreads();     // BN = 64: the next pass's first barrier already orders T reads before T writes
             }
+            if (SPLIT) __syncthreads();
+            if (!has_next) break;
+            item = nitem;
+            nitem = nnitem;
+            cur = nxt;
+            nxt = nn;
         }
-        if (!has_next) break;
-        item = nitem;
-        ib = nxb; inb = nxnb; itile = nxtile;
-        witem = wnitem;
     }
 #undef MICA_BLOAD16
 #undef MICA_SLAB_DMA
-#undef MICA_TILE_ORIGIN
     // nothing may still be in flight towards this workgroup's registers or LDS when it ends
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[W16_SET(0)][0]), "+v"(bq[W16_SET(0)][1]), "+v"(bq[W16_SET(0)][2]), "+v"(bq[W16_SET(0)][3]));
+#undef W16_SET
+#undef W16_NDMA
+#undef W16_DMA0
+#undef W16_XHI
+#undef W16_TAP
+#undef W16_AOFF
+#undef W16_ADELTA
+#undef W16_WOFF
+#undef W16_WDELTA
+#undef W16_SEL
 }
 
-static bool wino16_enabled(int cout) {
+// which layers take conv_wino16: Cout a multiple of 64 (block of 128 channels when possible, else 64); MICA_W16=0 (development)
+// sends everything back to conv_wino_kernel
+static int wino16_block(int cout) {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MICA_W16");
-        v = (e && e[0] == '0') ? 0 : 1;
+        v = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;     // 2: only the 128 blocks (development A/B)
     }
-    return v == 1 && cout % 128 == 0;
+    if (v == 0) return 0;
+    if (cout % 128 == 0) return 128;
+    return (v == 1 && cout % 64 == 0) ? 64 : 0;
 }
 
 static int launch_conv_wino16(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
                               float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
     int total = 0;
     for (int i = 0; i < s.n; ++i) total += s.chunks[i];
-    int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / 128;
+    const int bn = wino16_block(cout);
+    int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / bn;
     size_t lds = 2 * GeoW::CH_BYTES;
     static int cus = 0;
     if (!cus) {
         (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
@@ -1040,8 +1161,12 @@ static int launch_conv_wino16(const ConvSrcs& s, const _Float16* wpk, int64_t wp
     // one persistent workgroup per CU (LDS admits no more), a multiple of eight so that every XCD gets the same number
     const int items_per_b = ntx * nty * ntz * nnb, total_items = items_per_b * B;
     const int nwg = total_items >= cus ? cus : ((total_items + 7) / 8) * 8;
-    hipLaunchKernelGGL((conv_wino16_kernel<128>), dim3(nwg), dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout,
-                       total, ntx, nty, nnb, items_per_b, total_items, stats_ws);
+    if (bn == 128)
+        hipLaunchKernelGGL((conv_wino16_kernel<128>), dim3(nwg), dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
+                           cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws);
+    else
+        hipLaunchKernelGGL((conv_wino16_kernel<64>), dim3(nwg), dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
+                           cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws);
     return ntx * nty * ntz * 4;
 }
 
@@ -1067,7 +1192,7 @@ static int launch_conv_wino_t(const ConvSrcs& s, const _Float16* wpk, int64_t wp
 // f32 [B][P][cout][3] = (count, mean, M2), to be merged by launch_stats_finalize.
 int launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
                      float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
-    if (wino16_enabled(cout)) return launch_conv_wino16(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
+    if (wino16_block(cout)) return launch_conv_wino16(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
     if (cout % 128 == 0) return launch_conv_wino_t<128, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
     if (cout % 64 == 0) return launch_conv_wino_t<64, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
     return launch_conv_wino_t<32, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
@@ -1115,21 +1240,22 @@ __global__ void pack_weights_wino_kernel(const float* __restrict__ w, int cout, 
     *reinterpret_cast<half8*>(wpk + (int64_t)b * per_b + e * 8) = o;
 }
 
-// weights for conv_wino16: [B][nb = Cout/128][chunk][pair-step 5][p 4][unit 8][128][8] halves; unit u: 0,1 = hi of tap t
-// (k-half 0,1), 2,3 = hi of tap t' = t+1, 4,5 = lo of tap t, 6,7 = lo of tap t'; pair-step 4 is tap 8 alone (units 2,3,6,7 zero)
+// weights for conv_wino16: [B][nb = Cout/bn][chunk][pair-step 5][p 4][unit 8][bn][8] halves (bn = 128 or 64); unit u: 0,1 = hi
+// of tap t (k-half 0,1), 2,3 = hi of tap t' = t+1, 4,5 = lo of tap t, 6,7 = lo of tap t'; pair-step 4 is tap 8 alone (units
+// 2,3,6,7 zero)
 __global__ void pack_weights_wino16_kernel(const float* __restrict__ w, int cout, int cin, Segs sg, int total_chunks,
                                            const float* __restrict__ cin_scale, float mul, _Float16* __restrict__ wpk,
-                                           int64_t per_b) {
+                                           int64_t per_b, int bn) {
     const int b = blockIdx.y;
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [nb][chunk][ps][p][unit][n128]
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [nb][chunk][ps][p][unit][n in block]
     int64_t total = (int64_t)total_chunks * 5 * 4 * 8 * cout;
     if (e >= total) return;
-    int nl = e & 127;
-    int u = (e >> 7) & 7;
-    int pp = (e >> 10) & 3;
-    int ps = (e >> 12) % 5;
-    int gch = (e / (5 << 12)) % total_chunks;
-    int n = (int)(e / ((int64_t)(5 << 12) * total_chunks)) * 128 + nl;
+    int nl = e % bn;
+    int u = (e / bn) & 7;
+    int pp = (e / (bn * 8)) & 3;
+    int ps = (e / (bn * 32)) % 5;
+    int gch = (e / (bn * 160)) % total_chunks;
+    int n = (int)(e / ((int64_t)bn * 160 * total_chunks)) * bn + nl;
     const int kind = u >> 2, second = (u >> 1) & 1, kh = u & 1;
     const int tap = 2 * ps + second;
     half8 o;
@@ -1161,7 +1287,7 @@ __global__ void pack_weights_wino16_kernel(const float* __restrict__ w, int cout
 }
 
 int64_t packed_weight_halves_wino(int cout, int total_chunks) {
-    if (wino16_enabled(cout)) return (int64_t)total_chunks * 5 * 32 * cout * 8;
+    if (wino16_block(cout)) return (int64_t)total_chunks * 5 * 32 * cout * 8;
     return (int64_t)total_chunks * 9 * 16 * cout * 8;
 }
 
@@ -1175,11 +1301,11 @@ void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_se
         sg.cp[i] = h_seg_cp[i];
         total_chunks += h_seg_cp[i] / 16;
     }
-    if (wino16_enabled(cout)) {
+    if (wino16_block(cout)) {
         int64_t total16 = (int64_t)total_chunks * 5 * 32 * cout;
         dim3 grid16((unsigned)((total16 + 255) / 256), B);
         hipLaunchKernelGGL(pack_weights_wino16_kernel, grid16, dim3(256), 0, st, w, cout, cin, sg, total_chunks, cin_scale,
-                           cout_scale * wscale, wpk, packed_weight_halves_wino(cout, total_chunks));
+                           cout_scale * wscale, wpk, packed_weight_halves_wino(cout, total_chunks), wino16_block(cout));
         return;
     }
     int64_t total = (int64_t)total_chunks * 9 * 16 * cout;

@@ -210,18 +210,21 @@ def test_inline_asm_weight_prefetch_is_hazard_free(tmp_path):
         assert m.group(0).count("global_load_dwordx4") >= 18 and ".vgpr_spill_count" not in m.group(0)
         found += 1
     assert found == 3
-    # the persistent 16x16x32 variant: same audit with its LDS-DMA instructions occupying queue slots; per chunk 9 waits that
-    # leave the previous step's DMA in flight (vmcnt(5)), 5 + 1 plain ones, and exactly one copy of the 448-MFMA chunk body
-    m = re.search(r"^_ZN4mica18conv_wino16_kernelILi128E.*?s_endpgm", text, flags=re.S | re.M)
-    assert m
-    part = str(tmp_path / "wino16.s")
-    open(part, "w").write(m.group(0))
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), part], text=True)
-    assert "violations: 0" in out, out[-2000:]
-    body = m.group(0)
-    assert body.count("v_mfma_f32_16x16x32_f16") == 448 and body.count("s_waitcnt vmcnt(5)") == 9
-    assert body.count("s_waitcnt vmcnt(4)") == 6 and body.count("global_load_lds_dwordx4") == 18
-    assert "scratch_" not in body
+    # the persistent 16x16x32 variants: same audit with their LDS-DMA instructions occupying queue slots.  Per chunk and wave the
+    # 128-channel variant walks 14 steps (448 MFMAs; 9 waits that leave the previous step's one DMA in flight, 5 + 1 plain
+    # ones), the 64-channel variant 7 steps (224 MFMAs; previous step issued 2, 1 or 0 DMAs); one copy of the chunk body each
+    for bn, n_mfma, waits in ((128, 448, {5: 9, 4: 6}), (64, 224, {6: 3, 5: 3, 4: 2})):
+        m = re.search(r"^_ZN4mica18conv_wino16_kernelILi%dE.*?s_endpgm" % bn, text, flags=re.S | re.M)
+        assert m, bn
+        part = str(tmp_path / ("wino16_%d.s" % bn))
+        open(part, "w").write(m.group(0))
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), part], text=True)
+        assert "violations: 0" in out, out[-2000:]
+        body = m.group(0)
+        assert body.count("v_mfma_f32_16x16x32_f16") == n_mfma
+        for cnt, times in waits.items():
+            assert body.count("s_waitcnt vmcnt(%d)" % cnt) == times, (bn, cnt)
+        assert body.count("global_load_lds_dwordx4") == 18 and "scratch_" not in body
     # no kernel of the file spills (a spilled asm destination would be reloaded/stored around in-flight loads)
     spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
     assert spills and max(spills) == 0, spills

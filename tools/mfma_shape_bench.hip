@@ -9,8 +9,9 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 template <int SHAPE>
-__global__ __launch_bounds__(512, 2) void k(const half8* __restrict__ in, float* __restrict__ out, int iters) {
+__global__ __launch_bounds__(512, 2) void k(const half8* __restrict__ in, float* __restrict__ out, int iters, long long* __restrict__ cyc) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long t0 = clock64();
     half8 a[4], b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { a[i] = in[(tid * 8 + i) % 65536]; b[i] = in[(tid * 8 + 4 + i) % 65536]; }
@@ -30,6 +31,8 @@ __global__ __launch_bounds__(512, 2) void k(const half8* __restrict__ in, float*
 #pragma unroll
         for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
         out[tid] = s;
+        if (threadIdx.x == 0) cyc[blockIdx.x] = clock64() - t0;
+        return;
     } else {
         f4v acc[32];
 #pragma unroll
@@ -46,6 +49,7 @@ __global__ __launch_bounds__(512, 2) void k(const half8* __restrict__ in, float*
         for (int i = 0; i < 32; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j];
         out[tid] = s;
     }
+    if (threadIdx.x == 0) cyc[blockIdx.x] = clock64() - t0;
 }
 
 int main() {
@@ -56,16 +60,23 @@ int main() {
     hipMalloc(&din, h.size() * 2); hipMalloc(&dout, 256 * 512 * 4 * 4);
     hipMemcpy(din, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     const int iters = 20000;
-    for (int rep = 0; rep < 3; ++rep)
+    long long* dcyc; hipMalloc(&dcyc, 256 * 8);
+    for (int threads = 256; threads <= 512; threads += 256)
+    for (int rep = 0; rep < 2; ++rep)
         for (int shape = 0; shape < 2; ++shape) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0);
-            if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, din, dout, iters);
-            else hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, din, dout, iters);
+            if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, din, dout, iters, dcyc);
+            else hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, din, dout, iters, dcyc);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            double flops = 256.0 * 8 * iters * 24 * 32768.0;    // waves x iters x MFMA-equivalents
-            printf("shape %s: %.2f ms  %.1f TFLOP/s (f16 MFMA)\n", shape == 0 ? "32x32x16" : "16x16x32", ms, flops / ms / 1e9);
+            double flops = 256.0 * (threads / 64) * iters * 24 * 32768.0;    // waves x iters x MFMA-equivalents
+            std::vector<long long> hc(256); hipMemcpy(hc.data(), dcyc, 256 * 8, hipMemcpyDeviceToHost);
+            double cy = 0; for (auto v : hc) cy += (double)v / 256;
+            // MFMA pipe cycles one SIMD needs: (waves per SIMD) x iters x 24 x 32 cycles (32x32x16 = 8 passes; 16x16x32: two of 4 passes)
+            double need = (threads / 256) * (double)iters * 24 * 32;
+            printf("%d waves/SIMD shape %s: %.2f ms  %.1f TFLOP/s (f16 MFMA)  cycles %.0f  pipe busy %.3f  clock %.2f GHz\n", threads / 256,
+                   shape == 0 ? "32x32x16" : "16x16x32", ms, flops / ms / 1e9, cy, need / cy, cy / ms / 1e6);
         }
     return 0;
 }
