@@ -1081,8 +1081,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                         }
                     }
                     if (stats_ws) {
+                        // lanes of one 4-channel group sit CG apart: inside a row of 16 lanes they combine with DPP rotations
+                        // (VALU rate), the four rows with two cross-row exchanges
+#define W16_ROR_ADD(x, n) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (n), 0xf, 0xf, false))
+                        if (CG == 2) {
+                            W16_ROR_ADD(sn, 2);
 #pragma unroll
-                        for (int off = CG; off < 64; off <<= 1) {
+                            for (int c = 0; c < 4; ++c) { W16_ROR_ADD(s1[c], 2); W16_ROR_ADD(s2[c], 2); }
+                        }
+                        W16_ROR_ADD(sn, 4);
+                        W16_ROR_ADD(sn, 8);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { W16_ROR_ADD(s1[c], 4); W16_ROR_ADD(s2[c], 4); W16_ROR_ADD(s1[c], 8); W16_ROR_ADD(s2[c], 8); }
+#undef W16_ROR_ADD
+#pragma unroll
+                        for (int off = 16; off < 64; off <<= 1) {
                             sn += __shfl_xor(sn, off);
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
