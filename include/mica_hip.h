@@ -102,6 +102,16 @@ int mica_normalise_map(mica_ctx* ctx, float* d_vol, int64_t n, double* h_stats, 
 int mica_zoom_cubic(mica_ctx* ctx, const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1,
                     int64_t o2, float* d_out, void* stream);
 
+/* ---- AF3 encoding rasteriser: the atom loop of create_AF3_encodings (preprocessing.py:172-178, 283-298) ---- */
+/* d_xyz f32[n][3] atom coordinates (Angstrom, as Bio.PDB's float32 get_coord()), d_bb int32[n] = backbone channel 0..3
+ * ('CA','N','C','O', :254) or -1, d_aa int32[n] = amino-acid channel 4..23 (:255-260) or -1; h_origin = the map header's
+ * origin (x, y, z); (nz, ny, nx) = the normalised map's array shape.  Zeroes then fills d_vol f32[24][nz][ny][nx] with
+ * volume[ch, idx[2], idx[1], idx[0]] = 1, idx = clip(round(coord - origin), 0, shape - 1) with the reference's component
+ * order (x against nz, z against nx).  Returns MICA_ERR_RANGE where the reference raises IndexError (and so reports
+ * "AF3 encoding failed").  Synchronous.                                                               */
+int mica_rasterise_atoms(mica_ctx* ctx, const float* d_xyz, const int32_t* d_bb, const int32_t* d_aa, int64_t n_atoms,
+                         const float* h_origin, int64_t nz, int64_t ny, int64_t nx, float* d_vol, void* stream);
+
 /* ---- single-op entry points (parity tests drive each kernel through the ABI) -------------- */
 /* Conv3d k in {1,3}, stride 1, 'same' zero padding, on the split-f16 MFMA path.
  * d_x f32[B][Cin][D][H][W] NCDHW, h_w f32[Cout][Cin][k][k][k], h_b f32[Cout] -> d_y f32[B][Cout][D][H][W]. */

@@ -117,4 +117,8 @@ int normalise_map_device(float* d_vol, int64_t n, double* h_stats, hipStream_t s
 int zoom_cubic_device(const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1, int64_t o2, float* d_out,
                       hipStream_t st, char* err, int errlen);
 
+// AF3 encoding rasteriser (preprocessing.py:172-178,283-298) ; zeroes d_vol f32[24][nz][ny][nx] first ; synchronous
+int rasterise_atoms_device(const float* d_xyz, const int* d_bb, const int* d_aa, int64_t n_atoms, const float* origin, int64_t nz,
+                           int64_t ny, int64_t nx, float* d_vol, hipStream_t st, char* err, int errlen);
+
 }  // namespace mica

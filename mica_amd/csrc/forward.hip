@@ -756,6 +756,21 @@ int mica_zoom_cubic(mica_ctx* c, const float* d_in, int64_t n0, int64_t n1, int6
     return r;
 }
 
+int mica_rasterise_atoms(mica_ctx* c, const float* d_xyz, const int32_t* d_bb, const int32_t* d_aa, int64_t n_atoms,
+                         const float* h_origin, int64_t nz, int64_t ny, int64_t nx, float* d_vol, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (n_atoms < 0 || (n_atoms > 0 && (!d_xyz || !d_bb || !d_aa)) || !h_origin || !d_vol || nz < 1 || ny < 1 || nx < 1 || nz > 4096 ||
+        ny > 4096 || nx > 4096) {
+        c->err = "mica_rasterise_atoms: bad argument";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    char buf[256] = {0};
+    int r = rasterise_atoms_device(d_xyz, d_bb, d_aa, n_atoms, h_origin, nz, ny, nx, d_vol, (hipStream_t)stream, buf, sizeof(buf));
+    if (r) c->err = buf;
+    return r;
+}
+
 // ---- single-op entry points (test harness for the individual kernels) ---------------------------
 int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w, const float* h_b,
                    int cout, int k, float* d_y, void* stream) {

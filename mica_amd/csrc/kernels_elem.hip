@@ -2,6 +2,7 @@
 // with the split-f16 re-encoding the MFMA conv consumes, squeeze-excite style gate MLPs, head tails,
 // softmax/argmax post-processing, tile gather and stitch.  All f32 arithmetic; one pass over the data each.
 #include "common.h"
+#include <cstdio>
 
 namespace mica {
 
@@ -724,6 +725,58 @@ void launch_stitch_tiles(const float* tiles, int C, int64_t n0, int64_t n1, int6
     int nt1 = (int)((n1 + grid - 1) / grid), nt2 = (int)((n2 + grid - 1) / grid);
     dim3 g((unsigned)((G3 + 255) / 256), C, (unsigned)count);
     hipLaunchKernelGGL(stitch_tiles_kernel, g, dim3(256), 0, st, tiles, C, n0, n1, n2, grid, pad, first, nt1, nt2, vol);
+}
+
+// ---- AF3 encoding rasteriser: DataPreprocessor.create_AF3_encodings' atom loop (reference utils/preprocessing.py:172-178,
+// 283-298).  Per atom: idx = clip(round_half_even(float32(coord - origin)), 0, shape - 1) where `shape` is the map's
+// (nz, ny, nx) applied to the (x, y, z) components IN THAT ORDER (the reference's quirk: x is clipped against nz, z against
+// nx), then volume[ch, idx[2], idx[1], idx[0]] = 1 for the atom's backbone channel and its residue's amino-acid channel.
+// Where the reference would raise IndexError (non-cubic maps: clipped z index >= nz or x index >= nx) the flag is set.
+// Writes of 1.0 commute, so atom order does not matter.
+__device__ __forceinline__ long long af3_index(float c, float o, long long n) {
+    const float f = rintf(__fsub_rn(c, o));                       // np.round on float32: half to even
+    // numpy's float32 -> int64 cast (cvttss2si) gives INT64_MIN for NaN, +-inf and |f| >= 2^63; np.clip then makes it 0
+    if (!(fabsf(f) < 9.2233720368547758e18f)) return 0;
+    const long long i = (long long)f;
+    return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+}
+__global__ void rasterise_atoms_kernel(const float* __restrict__ xyz, const int* __restrict__ bb, const int* __restrict__ aa,
+                                       int64_t n_atoms, float ox, float oy, float oz, int64_t nz, int64_t ny, int64_t nx,
+                                       float* __restrict__ vol, int* __restrict__ flag) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_atoms) return;
+    const int cb = bb[a], ca = aa[a];
+    if (cb < 0 && ca < 0) return;
+    const long long i0 = af3_index(xyz[a * 3 + 0], ox, nz);       // x component, clipped against shape[0] = nz
+    const long long i1 = af3_index(xyz[a * 3 + 1], oy, ny);
+    const long long i2 = af3_index(xyz[a * 3 + 2], oz, nx);       // z component, clipped against shape[2] = nx
+    if (i2 >= nz || i0 >= nx) { atomicOr(flag, 1); return; }      // volume[ch, i2, i1, i0] would raise IndexError
+    const int64_t off = (i2 * ny + i1) * nx + i0, V = nz * ny * nx;
+    if (cb >= 0) vol[(int64_t)cb * V + off] = 1.0f;
+    if (ca >= 0) vol[(int64_t)ca * V + off] = 1.0f;
+}
+int rasterise_atoms_device(const float* d_xyz, const int* d_bb, const int* d_aa, int64_t n_atoms, const float* origin, int64_t nz,
+                           int64_t ny, int64_t nx, float* d_vol, hipStream_t st, char* err, int errlen) {
+    int* d_flag = nullptr;
+    if (hipMalloc(&d_flag, sizeof(int)) != hipSuccess) { snprintf(err, errlen, "mica_rasterise_atoms: hipMalloc failed"); return -2; }
+    int h_flag = 0;
+    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_vol, 0, (size_t)24 * nz * ny * nx * sizeof(float), st);
+    if (e == hipSuccess && n_atoms > 0) {
+        hipLaunchKernelGGL(rasterise_atoms_kernel, dim3((unsigned)((n_atoms + 255) / 256)), dim3(256), 0, st, d_xyz, d_bb, d_aa, n_atoms,
+                           origin[0], origin[1], origin[2], nz, ny, nx, d_vol, d_flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d_flag);
+    if (e != hipSuccess) { snprintf(err, errlen, "mica_rasterise_atoms: %s", hipGetErrorString(e)); return -2; }
+    if (h_flag) {
+        snprintf(err, errlen, "mica_rasterise_atoms: an atom indexes outside the volume (the reference raises IndexError: x is "
+                              "clipped against nz and z against nx, preprocessing.py:177,295)");
+        return -4;
+    }
+    return 0;
 }
 
 }  // namespace mica

@@ -176,6 +176,21 @@ class Engine:
         self._check(self.lib.mica_zoom_cubic(self._h, _ptr(vol), *n, *o, _ptr(out), _stream()), "mica_zoom_cubic")
         return out
 
+    def rasterise_atoms(self, xyz: torch.Tensor, bb: torch.Tensor, aa: torch.Tensor, origin, shape):
+        """Atoms -> f32[24, nz, ny, nx] AF3 encoding (preprocessing.py:283-298).  xyz f32[n,3], bb/aa int32[n] channel or -1;
+        origin = header origin (x, y, z); shape = (nz, ny, nx).  Raises MicaHipError where the reference raises IndexError."""
+        xyz = _f32c(xyz, "xyz")
+        n = xyz.shape[0]
+        for t, name in ((bb, "bb"), (aa, "aa")):
+            if t.dtype != torch.int32 or not t.is_contiguous() or t.device != xyz.device or t.numel() != n:
+                raise MicaHipError(f"{name} must be a contiguous int32 tensor of {n} entries on {xyz.device}")
+        nz, ny, nx = (int(v) for v in shape)
+        out = torch.empty((24, nz, ny, nx), dtype=torch.float32, device=self.device)
+        org = (C.c_float * 3)(*[float(np.float32(v)) for v in origin])
+        self._check(self.lib.mica_rasterise_atoms(self._h, _ptr(xyz), _ptr(bb), _ptr(aa), n, org, nz, ny, nx, _ptr(out), _stream()),
+                    "mica_rasterise_atoms")
+        return out
+
     # -- single ops (tests) -----------------------------------------------------------------------------
     def op_conv3d(self, x, w, b, k):
         x = _f32c(x, "x")

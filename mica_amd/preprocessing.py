@@ -4,7 +4,9 @@ GPU (exact median / 99.9th-percentile select, libmica_hip.so) and writes
 <dirname(AF3_results)>/resampled_normalized_map.mrc.
 
 The cubic-spline resample (scipy.ndimage.zoom(order=3), :117) also runs on the GPU (`mica_zoom_cubic`, f64, bit-exact
-against scipy).  `create_AF3_encodings` (PDB -> 24 rasters, needs Bio.PDB) is outside this build."""
+against scipy).  `create_AF3_encodings` (:225-347) rasterises the docked model's atoms on the GPU (`mica_rasterise_atoms`)
+and writes the 24 `<CH>_encoding.mrc` files; the PDB is read by a fixed-column reader (af3_encoding.py) because Bio.PDB
+is not installed - that parser step has no reference to be checked against here."""
 from __future__ import annotations
 
 import logging
@@ -61,6 +63,31 @@ class DataPreprocessor:
             self.logger.error(f"Map processing failed: {e}")
         self.print_clean("Map successfully resampled and normalized." if success else "Map Resampling and Normalization Failed")
 
-    def create_AF3_encodings(self, *a, **k):
-        raise NotImplementedError("AF3 encoding rasterisation (Bio.PDB based, preprocessing.py:225-347) is outside this build; "
-                                  "provide the 24 *_encoding.mrc files")
+    def encode_AF3_volume(self, combined_docked_model_path, origin, shape) -> torch.Tensor:
+        """The atom loop of create_AF3_encodings (:268-298) without the disk: float32 [24, nz, ny, nx] on the device."""
+        from . import af3_encoding
+
+        eng = self._engine or Engine(self._device, max_batch=1, tile_size=64)
+        self._engine = eng
+        coords, names, resnames = af3_encoding.read_pdb_atoms(combined_docked_model_path)
+        return af3_encoding.rasterise(eng, coords, names, resnames, origin, shape)
+
+    def create_AF3_encodings(self, combined_docked_model_path):
+        """Side effects and return value as preprocessing.py:225-347: reads the normalised map's header, writes
+        <dirname(AF3_results)>/AF3_encodings/<CH>_encoding.mrc for the 24 channels, returns True on success."""
+        from . import af3_encoding
+
+        success = False
+        try:
+            data, hd = mrc.read_mrc(self.normalized_map_path)
+            vol = self.encode_AF3_volume(combined_docked_model_path, hd.origin, data.shape).cpu().numpy()
+            self.AF3_encodings = os.path.join(os.path.dirname(self.AF3_results), 'AF3_encodings')
+            os.makedirs(self.AF3_encodings, exist_ok=True)
+            for ch, name in enumerate(af3_encoding.CHANNEL_NAMES):
+                mrc.write_mrc(os.path.join(self.AF3_encodings, f"{name}_encoding.mrc"), vol[ch], voxel_size=(1.0, 1.0, 1.0),
+                              origin=hd.origin, mapc=hd.mapc, mapr=hd.mapr, maps=hd.maps, nxstart=hd.nxstart,
+                              nystart=hd.nystart, nzstart=hd.nzstart)
+            success = True
+        except Exception as e:
+            self.print_clean(f"   Encoding failed: AF3 encoding failed: {e}")
+        return success

@@ -122,3 +122,50 @@ def test_sharded_records_gloo_world2(tmp_path, T, B):
     assert sorted(got) == sorted(single) == [f for f, _ in batch_plan(T, B)]
     for f in single:
         assert torch.equal(got[f], single[f])
+
+
+def _pdb_line(rec, serial, name, altloc, resname, chain, resseq, x, y, z, occ=1.0):
+    nm = name if len(name) == 4 else " " + name.ljust(3)
+    return "%-6s%5d %4s%1s%3s %1s%4d    %8.3f%8.3f%8.3f%6.2f%6.2f          %2s\n" % (
+        rec, serial, nm, altloc, resname, chain, resseq, x, y, z, occ, 20.0, name[0])
+
+
+def test_af3_pdb_reader_and_oracle_rasteriser(tmp_path):
+    """PDB reader of the docked model (fixed columns as PDBIO writes them; Bio is absent, so this step is pinned only by
+    files written here) and the oracle restatement of preprocessing.py:172-178,283-298."""
+    from mica_amd import af3_encoding as ae
+    from oracle import af3_oracle as ao
+
+    assert ae.CHANNEL_NAMES == ao.CHANNEL_NAMES and len(ae.CHANNEL_NAMES) == 24
+    lines = ["MODEL        1\n",
+             _pdb_line("ATOM", 1, "N", " ", "ALA", "A", 1, 1.2, 2.5, 3.5),        # 2.5 and 3.5 round half to even: 2, 4
+             _pdb_line("ATOM", 2, "CA", " ", "ALA", "A", 1, 2.49, 2.51, -0.4),
+             _pdb_line("ATOM", 3, "CB", "A", "ALA", "A", 1, 5.0, 5.0, 5.0, occ=0.3),
+             _pdb_line("ATOM", 4, "CB", "B", "ALA", "A", 1, 6.0, 6.0, 6.0, occ=0.7),  # higher occupancy altloc wins
+             _pdb_line("ATOM", 5, "O", " ", "MSE", "A", 2, 7.0, 1.0, 1.0),        # non-standard residue: backbone channel only
+             _pdb_line("HETATM", 6, "O", " ", "HOH", "A", 3, 3.0, 3.0, 3.0),      # hetero flag -> skipped
+             _pdb_line("ATOM", 7, "HD11", " ", "LEU", "B", 9, 100.0, -50.0, 4.4),  # hydrogen, clipped on both sides
+             "ENDMDL\n"]
+    pdb = tmp_path / "x_af3_docked.pdb"
+    pdb.write_text("".join(lines))
+    coords, names, res = ae.read_pdb_atoms(str(pdb))
+    assert names == ["N", "CA", "CB", "O", "HD11"] and res == ["ALA", "ALA", "ALA", "MSE", "LEU"]
+    assert coords.dtype == np.float32 and np.allclose(coords[2], [6, 6, 6])
+    bb, aa = ae.channel_indices(names, res)
+    assert bb.tolist() == [1, 0, -1, 3, -1] and aa.tolist() == [4, 4, 4, -1, 4 + 9]
+
+    shape = (9, 9, 9)
+    vol = ao.rasterise_atoms(coords, names, res, (0.0, 0.0, 0.0), shape)
+    assert vol.shape == (24, 9, 9, 9) and vol.dtype == np.float32
+    assert vol[1, 4, 2, 1] == 1 and vol[4, 4, 2, 1] == 1            # N of ALA at (x=1, y=2 (2.5 -> 2), z=4 (3.5 -> 4))
+    assert vol[0, 0, 3, 2] == 1                                       # CA: z = -0.4 -> 0
+    assert vol[4, 6, 6, 6] == 1 and vol[4, 5, 5, 5] == 0              # the altloc with occupancy 0.7
+    assert vol[3, 1, 1, 7] == 1 and vol[4:, 1, 1, 7].sum() == 0       # MSE: only the O channel
+    assert vol[13, 4, 0, 8] == 1                                      # LEU hydrogen, clipped to (8, 0, 4)
+    assert vol.sum() == 2 + 2 + 1 + 1 + 1
+    # the reference clips x against shape[0] (nz) and z against shape[2] (nx): on a non-cubic map a far-out z raises
+    with pytest.raises(IndexError):
+        ao.rasterise_atoms(np.array([[0, 0, 30]], np.float32), ["CA"], ["GLY"], (0, 0, 0), (4, 5, 40))
+    # ... and x beyond nz-1 is silently clipped to nz-1
+    v2 = ao.rasterise_atoms(np.array([[30, 0, 0]], np.float32), ["CA"], ["GLY"], (0, 0, 0), (4, 5, 40))
+    assert v2[0, 0, 0, 3] == 1

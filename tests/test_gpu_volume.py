@@ -284,3 +284,67 @@ def test_full_size_512_map_tiling_properties(eng):
     from mica_amd._cabi import tile_table
     tab = tile_table(512, 512, 512, 48)
     assert tab[-1].tolist() == [480, 480, 480, 32, 32, 32] and tab[0].tolist() == [0, 0, 0, 48, 48, 48]
+
+
+def _random_atoms(n, shape, seed):
+    from oracle import af3_oracle as ao
+    rng = np.random.default_rng(seed)
+    nz, ny, nx = shape
+    coords = (rng.random((n, 3), dtype=np.float32) * np.array([nx + 6, ny + 6, nz + 6], np.float32) - 3.0).astype(np.float32)
+    coords[: n // 8] = np.floor(coords[: n // 8]) + 0.5                  # exact halves: round half to even
+    names = [["CA", "N", "C", "O", "CB", "CG", "HA", "OXT"][i] for i in rng.integers(0, 8, n)]
+    res = [(ao.AMINO_ACIDS + ["MSE", "UNK"])[i] for i in rng.integers(0, 22, n)]
+    return coords, names, res
+
+
+@pytest.mark.parametrize("shape,origin", [((20, 20, 20), (0.0, 0.0, 0.0)), ((33, 17, 25), (-3.25, 4.5, 1.125)), ((12, 40, 12), (100.5, -7.0, 2.0))])
+def test_af3_rasteriser_bit_exact_vs_oracle(eng, shape, origin):
+    """mica_rasterise_atoms against the numpy restatement of preprocessing.py:172-178,283-298 (parity unpinned against the
+    reference itself: Bio/mrcfile absent).  Shapes with nz >= max index reach keep the reference from raising."""
+    from mica_amd import af3_encoding as ae
+    from oracle import af3_oracle as ao
+    coords, names, res = _random_atoms(4000, shape, 5)
+    coords = coords + np.array(origin, np.float32)
+    nz, ny, nx = shape
+    if nz != nx:        # keep x within nx and z within nz so that the reference's cross-axis clip never indexes out
+        coords[:, 0] = np.clip(coords[:, 0], origin[0], origin[0] + min(nx, nz) - 1)
+        coords[:, 2] = np.clip(coords[:, 2], origin[2], origin[2] + min(nx, nz) - 1)
+    ref = ao.rasterise_atoms(coords, names, res, origin, shape)
+    got = ae.rasterise(eng, coords, names, res, origin, shape).cpu().numpy()
+    assert got.shape == ref.shape and got.dtype == np.float32
+    assert np.array_equal(got, ref) and ref.sum() > 1000
+
+
+def test_af3_rasteriser_edge_cases(eng, tmp_path):
+    from mica_amd import af3_encoding as ae, mrc
+    from mica_amd.engine import MicaHipError
+    from mica_amd.preprocessing import DataPreprocessor
+    from oracle import af3_oracle as ao
+    # NaN / inf / huge coordinates: numpy's float->int cast gives INT64_MIN, clipped to 0
+    coords = np.array([[np.nan, 1, 1], [np.inf, 2, 2], [-np.inf, 3, 3], [3e38, 4, 4], [1e10, 5, 5], [-1e10, 6, 6]], np.float32)
+    names, res = ["CA"] * 6, ["GLY"] * 6
+    ref = ao.rasterise_atoms(coords, names, res, (0, 0, 0), (8, 8, 8))
+    got = ae.rasterise(eng, coords, names, res, (0, 0, 0), (8, 8, 8)).cpu().numpy()
+    assert np.array_equal(got, ref) and got[0, 1, 1, 0] == 1 and got[0, 5, 5, 7] == 1
+    # no atoms -> zeros; atoms without any channel -> zeros
+    assert ae.rasterise(eng, np.zeros((0, 3), np.float32), [], [], (0, 0, 0), (4, 4, 4)).sum().item() == 0
+    assert ae.rasterise(eng, np.ones((3, 3), np.float32), ["CB"] * 3, ["UNK"] * 3, (0, 0, 0), (4, 4, 4)).sum().item() == 0
+    # where the reference raises IndexError the library reports MICA_ERR_RANGE
+    with pytest.raises(IndexError):
+        ao.rasterise_atoms(np.array([[0, 0, 30]], np.float32), ["CA"], ["GLY"], (0, 0, 0), (4, 5, 40))
+    with pytest.raises(MicaHipError):
+        ae.rasterise(eng, np.array([[0, 0, 30]], np.float32), ["CA"], ["GLY"], (0, 0, 0), (4, 5, 40))
+    # the DataPreprocessor mirror: 24 MRC files with the map's header, readable by the tiler mirror
+    shape = (16, 16, 16)
+    mrc.write_mrc(str(tmp_path / "resampled_normalized_map.mrc"), np.zeros(shape, np.float32), origin=(1.0, 2.0, 3.0), nxstart=4)
+    pdb = tmp_path / "t_af3_docked.pdb"
+    pdb.write_text("ATOM      1  CA  GLY A   1       6.000   7.000   8.000  1.00 20.00           C\n")
+    (tmp_path / "af3").mkdir()
+    dp = DataPreprocessor(str(tmp_path / "map.mrc"), str(tmp_path / "af3"), quiet=True, engine=eng)
+    dp.normalized_map_path = str(tmp_path / "resampled_normalized_map.mrc")
+    assert dp.create_AF3_encodings(str(pdb)) is True
+    ca, hd = mrc.read_mrc(str(tmp_path / "AF3_encodings" / "CA_encoding.mrc"))
+    gly, _ = mrc.read_mrc(str(tmp_path / "AF3_encodings" / "GLY_encoding.mrc"))
+    assert ca[5, 5, 5] == 1 and ca.sum() == 1 and gly[5, 5, 5] == 1 and hd.origin == (1.0, 2.0, 3.0) and hd.nxstart == 4
+    assert len(list((tmp_path / "AF3_encodings").glob("*_encoding.mrc"))) == 24
+    assert dp.create_AF3_encodings(str(tmp_path / "missing.pdb")) is False
