@@ -1436,22 +1436,25 @@ void launch_pack_weights(const float* w, int cout, int cin, int ksize, const int
 // halo'd z planes in LDS (18 x 18 voxels x 16 channels x 4 B = 20.7 KB each): every input element is read from HBM
 // once per column (x/y halo 1.27x, no z re-reads), normalised once when it enters the ring, and the 27 taps
 // come from LDS.  Thread = (channel quad, x, 4 consecutive y) with a sliding window along y.
-constexpr int DW_X = 16, DW_C = 16;
+constexpr int DW_X = 16;
 constexpr int DW_LX = DW_X + 2;
 // YO = y outputs per thread: the column is 16(x) x 4*YO(y); YO = 2 doubles the number of workgroups for small C * batch
-template <int YO> struct DwGeo {
-    static constexpr int Y = 4 * YO, LY = Y + 2;
-    static constexpr int PLANE = DW_LX * LY * DW_C;     // floats per ring plane
+// CQ = channel quads per workgroup (64 * CQ threads): 4 = 16 channels, two workgroups per CU; 8 = 32 channels = one full
+// 128-B line per voxel, one workgroup of eight waves per CU.  With 16 channels every access is a 64-B piece of a 1-KB
+// voxel row and the kernel saturated at ~4.5 TB/s of actual traffic; prep-style contiguous streams reach 5.4.
+template <int YO, int CQ> struct DwGeo {
+    static constexpr int Y = 4 * YO, LY = Y + 2, DWC = 4 * CQ, NT = 64 * CQ;
+    static constexpr int PLANE = DW_LX * LY * DWC;     // floats per ring plane
 };
 
-template <int YO>
-__global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restrict__ x, Dims d, int C,
+template <int YO, int CQ>
+__global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(const float* __restrict__ x, Dims d, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ scale, const float* __restrict__ w27,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         float* __restrict__ stats_ws, int ntx, int nty) {
     extern __shared__ __attribute__((aligned(16))) float ring[];   // [3][LY][LX][16] ; reused for the statistics merge
-    constexpr int DW_Y = DwGeo<YO>::Y, DW_LY = DwGeo<YO>::LY, DW_PLANE = DwGeo<YO>::PLANE;
+    constexpr int DW_Y = DwGeo<YO, CQ>::Y, DW_LY = DwGeo<YO, CQ>::LY, DW_PLANE = DwGeo<YO, CQ>::PLANE, DW_C = 4 * CQ, NT = 64 * CQ;
     const int b = blockIdx.y;
     const int V = d.D * d.H * d.W;
     const int tid = threadIdx.x;
@@ -1464,57 +1467,56 @@ __global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restri
     const int tx = col % ntx, ty = col / ntx;
     const int x0 = tx * DW_X, y0 = ty * DW_Y, c0 = cs * DW_C;
 
-    const int cq = tid & 3, xi = (tid >> 2) & 15, yq = tid >> 6;     // compute role: 4 channels, x, YO y outputs
+    const int cq = tid % CQ, xi = (tid / CQ) & 15, yq = tid / (CQ * 16);     // compute role: 4 channels, x, YO y outputs
     const int c = c0 + cq * 4;
     float* wl = ring + 3 * DW_PLANE;                                  // [27][16] weights of this channel slab
-    for (int e = tid; e < 27 * DW_C; e += 256) wl[e] = w27[(e >> 4) * C + c0 + (e & 15)];
+    for (int e = tid; e < 27 * DW_C; e += NT) wl[e] = w27[(e / DW_C) * C + c0 + (e % DW_C)];
     const float4 bv = *reinterpret_cast<const float4*>(bias + c);
 
     // load role: plane elements (voxel, channel quad): 324 voxels x 4 quads = 1296 float4 per plane, <= 6 per thread.
-    // A plane is fetched into registers one step ahead (HBM latency hides under the previous plane's FMAs),
-    // normalised once, and written to the ring slot of the plane that has just been retired.
-    constexpr int NE = (DW_LX * DW_LY * 4 + 255) / 256;
-    float4 pre[NE];
-    // the channel quad of a thread's elements is (tid + 256 k) & 3 = tid & 3: one set of norm constants
-    const int lq = tid & 3;
+    // Planes are fetched RAW into registers THREE steps ahead (three register sets): at 2 workgroups per CU one plane in
+    // flight is 41 KB per CU, which at 2.5 us of loaded HBM latency caps the chip at 4.2 TB/s of actual traffic (Little's
+    // law) - that was the limit of the one-ahead version (2.6 -> 3.1 TB/s algorithmic).  A plane is normalised (IN-apply +
+    // ReLU + gate) when it is written to the ring slot of the plane that has just been retired.
+    constexpr int NE = (DW_LX * DW_LY * CQ + NT - 1) / NT;
+    float4 preA[NE], preB[NE], preC[NE];
+    // the channel quad of a thread's elements is (tid + NT k) % CQ = tid % CQ: one set of norm constants
+    const int lq = tid % CQ;
     float4 nm = make_float4(0, 0, 0, 0), nr = make_float4(1, 1, 1, 1), ns = make_float4(1, 1, 1, 1);
     if (mean) { nm = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c0 + lq * 4); nr = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c0 + lq * 4); }
     if (scale) ns = *reinterpret_cast<const float4*>(scale + (int64_t)b * C + c0 + lq * 4);
-    auto fetch_plane = [&](int gz) {
+    auto fetch_plane = [&](int gz, float4 (&pre)[NE]) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = tid + NT * k;
+            const int v = e / CQ;
+            const int lx = v % DW_LX, ly = v / DW_LX;
+            const int cx = min(max(x0 + lx - 1, 0), d.W - 1), cy = min(max(y0 + ly - 1, 0), d.H - 1), cz = min(max(gz, 0), d.D - 1);
+            pre[k] = *reinterpret_cast<const float4*>(x + ((int64_t)b * V + (int64_t)(cz * d.H + cy) * d.W + cx) * C + c0 + lq * 4);
+        }
+    };
+    auto store_plane = [&](int slot, int gz, float4 (&pre)[NE]) {
+        float* dst = ring + slot * DW_PLANE;
         const bool zok = (unsigned)gz < (unsigned)d.D;
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const int e = tid + 256 * k;
-            const int q = lq, v = e >> 2;
+            const int e = tid + NT * k;
+            const int v = e / CQ;
             const int lx = v % DW_LX, ly = v / DW_LX;
-            const int gx = x0 + lx - 1, gy = y0 + ly - 1;
-            const bool ok = zok && e < DW_LX * DW_LY * 4 && (unsigned)gx < (unsigned)d.W && (unsigned)gy < (unsigned)d.H;
-            const int cx = min(max(gx, 0), d.W - 1), cy = min(max(gy, 0), d.H - 1), cz = min(max(gz, 0), d.D - 1);
-            float4 t = *reinterpret_cast<const float4*>(x + ((int64_t)b * V + (int64_t)(cz * d.H + cy) * d.W + cx) * C + c0 + q * 4);
+            const bool ok = zok && (unsigned)(x0 + lx - 1) < (unsigned)d.W && (unsigned)(y0 + ly - 1) < (unsigned)d.H;
+            float4 t = pre[k];
             if (mean) {
                 t.x = fmaxf((t.x - nm.x) * nr.x, 0.f) * ns.x; t.y = fmaxf((t.y - nm.y) * nr.y, 0.f) * ns.y;
                 t.z = fmaxf((t.z - nm.z) * nr.z, 0.f) * ns.z; t.w = fmaxf((t.w - nm.w) * nr.w, 0.f) * ns.w;
             } else { t.x *= ns.x; t.y *= ns.y; t.z *= ns.z; t.w *= ns.w; }
-            pre[k] = ok ? t : make_float4(0, 0, 0, 0);
-        }
-    };
-    auto store_plane = [&](int slot) {
-        float* dst = ring + slot * DW_PLANE;
-#pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            const int e = tid + 256 * k;
-            if (e < DW_LX * DW_LY * 4) *reinterpret_cast<float4*>(dst + (e >> 2) * DW_C + (e & 3) * 4) = pre[k];
+            if (!ok) t = make_float4(0, 0, 0, 0);
+            if (e < DW_LX * DW_LY * CQ) *reinterpret_cast<float4*>(dst + v * DW_C + lq * 4) = t;
         }
     };
 
     float sn = 0.f;
     float4 sk = make_float4(0, 0, 0, 0), s1 = sk, s2 = sk;
-    fetch_plane(-1); store_plane(0);
-    fetch_plane(0);  store_plane(1);
-    fetch_plane(1);  store_plane(2);
-    __syncthreads();
-    for (int z = 0; z < d.D; ++z) {
-        fetch_plane(z + 2);                 // in flight during this plane's arithmetic
+    auto compute_plane = [&](int z) {
         float4 acc[YO];
 #pragma unroll
         for (int i = 0; i < YO; ++i) acc[i] = bv;
@@ -1551,13 +1553,35 @@ __global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restri
                 sn += 1.f;
             }
         }
+    };
+    fetch_plane(-1, preA); fetch_plane(0, preB); fetch_plane(1, preC);
+    store_plane(0, -1, preA); store_plane(1, 0, preB); store_plane(2, 1, preC);
+    fetch_plane(2, preA); fetch_plane(3, preB);
+    __syncthreads();
+    // invariant at the top of an iteration z (multiple of 3): preA holds plane z + 2 and preB plane z + 3 (in flight), the
+    // ring holds z-1, z, z+1
+    for (int z = 0; z < d.D; z += 3) {
+        fetch_plane(z + 4, preC);
+        compute_plane(z);
         __syncthreads();                    // plane z-1 (slot z % 3) is no longer read by anyone
-        store_plane(z % 3);                 // plane z+2 takes its place
+        store_plane(z % 3, z + 2, preA);    // plane z+2 takes its place
+        __syncthreads();
+        if (z + 1 >= d.D) break;
+        fetch_plane(z + 5, preA);
+        compute_plane(z + 1);
+        __syncthreads();
+        store_plane((z + 1) % 3, z + 3, preB);
+        __syncthreads();
+        if (z + 2 >= d.D) break;
+        fetch_plane(z + 6, preB);
+        compute_plane(z + 2);
+        __syncthreads();
+        store_plane((z + 2) % 3, z + 4, preC);
         __syncthreads();
     }
     if (!stats_ws) return;
     // block merge of (count, mean, M2): 64 threads (x, yq) share a channel quad
-    float* shn = ring; float* shm = ring + 1024; float* shq = ring + 2048;
+    float* shn = ring; float* shm = ring + 4 * NT; float* shq = ring + 8 * NT;
     const float kk[4] = {sk.x, sk.y, sk.z, sk.w}, a1[4] = {s1.x, s1.y, s1.z, s1.w}, a2[4] = {s2.x, s2.y, s2.z, s2.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1566,10 +1590,10 @@ __global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restri
         shn[tid * 4 + j] = sn; shm[tid * 4 + j] = mean_; shq[tid * 4 + j] = m2;
     }
     __syncthreads();
-    const int rl = tid >> 2;                       // 0..63 within the channel quad
+    const int rl = tid / CQ;                       // 0..63 within the channel quad
     for (int off = 32; off > 0; off >>= 1) {
         if (rl < off) {
-            const int o = tid + off * 4;
+            const int o = tid + off * CQ;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float na = shn[tid * 4 + j], ma = shm[tid * 4 + j], qa = shq[tid * 4 + j];
@@ -1591,21 +1615,39 @@ __global__ __launch_bounds__(256, 2) void depthwise_kernel(const float* __restri
 }
 
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null).
+template <int YO, int CQ>
+static void launch_depthwise_t(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, const float* scale,
+                               const float* w27, const float* bias, float* out, float* stats_ws, int ntx, int nty, hipStream_t st) {
+    using Gm = DwGeo<YO, CQ>;
+    const size_t lds = (3 * Gm::PLANE + 27 * Gm::DWC) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)depthwise_kernel<YO, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    dim3 grid((unsigned)(ntx * nty * (C / Gm::DWC)), B);
+    hipLaunchKernelGGL((depthwise_kernel<YO, CQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty);
+}
 int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, hipStream_t st) {
     const int ntx = (d.W + DW_X - 1) / DW_X;
+    static int wide = -1;
+    if (wide < 0) {
+        const char* e = getenv("MICA_DW_WIDE");
+        wide = (e && e[0] == '0') ? 0 : 1;
+    }
+    // 32-channel workgroups (full 128-B lines) when that still gives every CU at least two rounds of work
+    if (wide && C % 32 == 0 && (int64_t)ntx * ((d.H + 15) / 16) * (C / 32) * B >= 512) {
+        const int nty = (d.H + 15) / 16;
+        launch_depthwise_t<4, 8>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty, st);
+        return ntx * nty;
+    }
     // enough workgroups to fill 256 CUs twice: halve the column height when C * batch is small
-    const bool small = (int64_t)ntx * ((d.H + 15) / 16) * (C / DW_C) * B < 1024;
+    const bool small = (int64_t)ntx * ((d.H + 15) / 16) * (C / 16) * B < 1024;
     const int Y = small ? 8 : 16;
     const int nty = (d.H + Y - 1) / Y;
-    dim3 grid((unsigned)(ntx * nty * (C / DW_C)), B);
-    if (small) {
-        const size_t lds = (3 * DwGeo<2>::PLANE + 27 * DW_C) * sizeof(float);
-        hipLaunchKernelGGL(depthwise_kernel<2>, grid, dim3(256), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty);
-    } else {
-        const size_t lds = (3 * DwGeo<4>::PLANE + 27 * DW_C) * sizeof(float);
-        hipLaunchKernelGGL(depthwise_kernel<4>, grid, dim3(256), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty);
-    }
+    if (small) launch_depthwise_t<2, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty, st);
+    else launch_depthwise_t<4, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty, st);
     return ntx * nty;
 }
 
