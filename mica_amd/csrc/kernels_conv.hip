@@ -14,204 +14,10 @@ namespace mica {
 
 struct Segs { int c[MAX_SRC]; int cp[MAX_SRC]; int n; };   // channel segmentation of a conv's concatenated input
 
-// ------------------------------------------------------------------------------------------------
-// Geometry of one workgroup (256 threads = 4 waves): output tile 16(x) x 8(y) x 2(z) voxels = 256 GEMM
-// rows, BN output channels.  Wave w owns rows y = 2w, 2w+1; an MFMA row-fragment (32 rows) is the 16 x
-// of one y in both z planes, which makes every ds_read_b128 lane group hit 16 distinct 16-B LDS slots
-// (the z-plane stride is padded to a multiple of 16 slots).
-// LDS A image: 4 planes q = kind*2 + khalf (kind: hi/lo, khalf: channels 0-7 / 8-15 of the chunk), each
-// [SZ][PZ] slots of 16 B (8 halves); slot = vz*PZ + vy*SX + vx.
-// ------------------------------------------------------------------------------------------------
-template <int KS> struct Geo {
-    static constexpr int HALO = KS / 2;
-    static constexpr int SX = 16 + 2 * HALO, SY = 8 + 2 * HALO, SZ = 2 + 2 * HALO;
-    static constexpr int PZ = ((SX * SY + 15) / 16) * 16;     // slots per z plane, = 0 mod 16
-    static constexpr int PLANE = SZ * PZ;                     // slots per q plane
-    static constexpr int A_BYTES = 4 * PLANE * 16;
-    static constexpr int NT = KS * KS * KS;
-    static constexpr int ROW_PIECES = SX * 4;                 // 16-B pieces per slab row (contiguous in HBM)
-    static constexpr int PIECES = SZ * SY * ROW_PIECES;
-};
-
-template <int KS, int BN>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvSrcs s, const _Float16* __restrict__ wpk,
-                                                           int64_t wpk_bstride, const float* __restrict__ bias,
-                                                           float out_scale, float* __restrict__ out, Dims d,
-                                                           int cout, int total_chunks, int ntx, int nty, int nnb) {
-    using G = Geo<KS>;
-    constexpr int NJ = BN / 32;
-    constexpr int B_BYTES = 4 * BN * 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsA = smem;
-    char* ldsB = smem + G::A_BYTES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int V = d.D * d.H * d.W;
-
-    // XCD-aware remap: blocks id, id+8, ... share an XCD (round-robin dispatch); give each XCD a
-    // contiguous run of (tile, n-block) pairs so halo-sharing neighbours meet in one L2.
-    int id = blockIdx.x;
-    const int nwg = gridDim.x;
-    if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
-    const int nb = id % nnb;
-    const int tile = id / nnb;
-    const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
-    const int x0 = tx * 16 - G::HALO, y0 = ty * 8 - G::HALO, z0 = tz * 2 - G::HALO;
-
-    floatx16 acc[2][NJ];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[f][j][i] = 0.f;
-
-    const _Float16* wbase = wpk + (int64_t)b * wpk_bstride + (int64_t)nb * BN * 8;
-    // B staging: piece p = q*BN + n  ->  LDS byte p*16 ; global ((step*4 + q)*cout + n)*8 halves.
-    // Two named registers (not an array behind a lambda: that ends up in scratch and serialises the prefetch).
-    constexpr bool B2 = (4 * BN > 256);          // BN=128: two pieces per thread
-    constexpr bool BPART = (4 * BN < 256);       // BN=32: only the first 128 threads stage
-    const int bp0 = tid, bp1 = tid + 256;
-    const int64_t boff0 = ((int64_t)(bp0 / BN) * cout + (bp0 % BN)) * 8;
-    const int64_t boff1 = ((int64_t)(bp1 / BN) * cout + (bp1 % BN)) * 8;
-    const int64_t bstep = (int64_t)4 * cout * 8;
-    uint4 breg0 = make_uint4(0, 0, 0, 0), breg1 = make_uint4(0, 0, 0, 0);
-#define MICA_LOADB(step)                                                                                   \
-    do {                                                                                                   \
-        if (!BPART || tid < 4 * BN) breg0 = *reinterpret_cast<const uint4*>(wbase + (step) * bstep + boff0); \
-        if (B2) breg1 = *reinterpret_cast<const uint4*>(wbase + (step) * bstep + boff1);                    \
-    } while (0)
-#define MICA_STOREB(buf)                                                                                   \
-    do {                                                                                                   \
-        if (!BPART || tid < 4 * BN) *reinterpret_cast<uint4*>(ldsB + (buf) * B_BYTES + bp0 * 16) = breg0;   \
-        if (B2) *reinterpret_cast<uint4*>(ldsB + (buf) * B_BYTES + bp1 * 16) = breg1;                       \
-    } while (0)
-
-    // per-lane LDS read bases (bytes)
-    const int lx = lane & 15, lzz = (lane >> 4) & 1, lh = lane >> 5;
-    const int a_base = (lh * G::PLANE + lzz * G::PZ + (2 * wave) * G::SX + lx) * 16;
-    const int b_base = (lh * BN + (lane & 31)) * 16;
-
-    const int nsteps = total_chunks * G::NT;
-    MICA_LOADB(0);
-    MICA_STOREB(0);
-
-    int gch = 0;
-    for (int si = 0; si < s.n; ++si) {
-        for (int ch = 0; ch < s.chunks[si]; ++ch, ++gch) {
-            // ---- stage the halo'd A slab of this 16-channel chunk ------------------------------
-            // All loads are issued unconditionally from clamped (always valid) addresses and zeroed by a
-            // select afterwards: a branch around each load would make hipcc wait vmcnt(0) per piece,
-            // i.e. NP dependent HBM round trips per chunk.
-            const _Float16* src =
-                s.p[si] + ((int64_t)b * s.chunks_total[si] + s.chunk_off[si] + ch) * (int64_t)V * 32;
-            constexpr int NP = (G::PIECES + 255) / 256;
-            uint4 av[NP];
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                int p = tid + 256 * i;
-                p = p < G::PIECES ? p : G::PIECES - 1;
-                int row = p / G::ROW_PIECES, within = p - row * G::ROW_PIECES;
-                int vx = within >> 2, q = within & 3;
-                int vy = row % G::SY, vz = row / G::SY;
-                int gx = min(max(x0 + vx, 0), d.W - 1), gy = min(max(y0 + vy, 0), d.H - 1), gz = min(max(z0 + vz, 0), d.D - 1);
-                av[i] = *reinterpret_cast<const uint4*>(src + ((int64_t)(gz * d.H + gy) * d.W + gx) * 32 + q * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                int p = tid + 256 * i;
-                int pc = p < G::PIECES ? p : G::PIECES - 1;
-                int row = pc / G::ROW_PIECES, within = pc - row * G::ROW_PIECES;
-                int vx = within >> 2, q = within & 3;
-                int vy = row % G::SY, vz = row / G::SY;
-                int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
-                bool ok = (unsigned)gx < (unsigned)d.W && (unsigned)gy < (unsigned)d.H && (unsigned)gz < (unsigned)d.D;
-                uint4 v = av[i];
-                v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-                if (p < G::PIECES)
-                    *reinterpret_cast<uint4*>(ldsA + (q * G::PLANE + vz * G::PZ + vy * G::SX + vx) * 16) = v;
-            }
-            __syncthreads();
-            // ---- taps --------------------------------------------------------------------------
-#pragma unroll
-            for (int tap = 0; tap < G::NT; ++tap) {
-                const int g = gch * G::NT + tap;
-                const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-                if (g + 1 < nsteps) MICA_LOADB(g + 1);
-                const char* Bb = ldsB + (g & 1) * B_BYTES;
-                half8 a[2][2];
-#pragma unroll
-                for (int f = 0; f < 2; ++f)
-#pragma unroll
-                    for (int kind = 0; kind < 2; ++kind)
-                        a[f][kind] = *reinterpret_cast<const half8*>(
-                            ldsA + a_base + (kind * 2 * G::PLANE + dz * G::PZ + (f + dy) * G::SX + dx) * 16);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    half8 bh = *reinterpret_cast<const half8*>(Bb + b_base + (j * 32) * 16);
-                    half8 bl = *reinterpret_cast<const half8*>(Bb + b_base + (2 * BN + j * 32) * 16);
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][1], bh, acc[f][j], 0, 0, 0);
-                        acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bl, acc[f][j], 0, 0, 0);
-                        acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bh, acc[f][j], 0, 0, 0);
-                    }
-                }
-                if (g + 1 < nsteps) MICA_STOREB((g + 1) & 1);
-                __syncthreads();
-            }
-        }
-    }
-
-#undef MICA_LOADB
-#undef MICA_STOREB
-    // ---- epilogue: out[b][voxel][n] = acc*out_scale + bias[n] ------------------------------------
-    // C/D map of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
-    const int col = lane & 31, rhalf = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = nb * BN + j * 32 + col;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const int gy = ty * 8 + 2 * wave + f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = (i & 3) + 8 * (i >> 2) + 4 * rhalf;
-                const int gx = tx * 16 + (r & 15), gz = tz * 2 + (r >> 4);
-                if (gx < d.W && gy < d.H && gz < d.D)
-                    out[((int64_t)b * V + (int64_t)(gz * d.H + gy) * d.W + gx) * cout + n] =
-                        acc[f][j][i] * out_scale + bv;
-            }
-        }
-    }
-}
-
-template <int KS, int BN>
-static void launch_conv_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
-                          float out_scale, float* out, int B, Dims d, int cout, hipStream_t st) {
-    using G = Geo<KS>;
-    int total = 0;
-    for (int i = 0; i < s.n; ++i) total += s.chunks[i];
-    int ntx = (d.W + 15) / 16, nty = (d.H + 7) / 8, ntz = (d.D + 1) / 2, nnb = cout / BN;
-    size_t lds = G::A_BYTES + 2 * 4 * BN * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KS, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    dim3 grid(ntx * nty * ntz * nnb, B);
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, BN>), grid, dim3(256), lds, st, s, wpk, wpk_bstride, bias, out_scale,
-                       out, d, cout, total, ntx, nty, nnb);
-}
-
-
 // ================================================================================================
-// conv2: the same arithmetic, restructured around the measured stalls of the kernel above (57 % of the
-// wave-cycles waited at the per-tap barrier / B hand-off):
+// conv2 (direct conv; now the 1x1x1 convs and the MICA_WINO=0 fallback): structured around the measured stalls of the
+// first version (four-wave workgroups staging A and B through LDS per tap: 57 % of the wave-cycles waited at the per-tap
+// barrier / B hand-off; removed from the tree):
 //   * one 8-wave workgroup per CU, output tile 16(x) x 8(y) x 4(z) = 512 GEMM rows x BN channels
 //     (halo overhead 2.1x instead of 2.8x, weights fetched once per 512 rows);
 //   * the halo'd A slab is DOUBLE-buffered in LDS and filled by LDS-DMA (global_load_lds, 16 B/lane, no
@@ -1327,39 +1133,18 @@ void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_se
                        cout_scale * wscale, wpk, packed_weight_halves_wino(cout, total_chunks));
 }
 
-static int conv_impl() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MICA_CONV_IMPL");
-        v = (e && e[0] == '1') ? 1 : 2;
-    }
-    return v;
-}
-
 void launch_conv_mfma(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
                       float out_scale, float* out, int B, Dims d, int cout, int ksize, int* /*errflag*/,
                       hipStream_t st) {
     // cout is always a multiple of 32 here (small heads go through launch_head_final)
-    if (conv_impl() == 2) {
-        if (ksize == 3) {
-            if (cout % 128 == 0) launch_conv2_t<3, 128, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-            else if (cout % 64 == 0) launch_conv2_t<3, 64, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-            else launch_conv2_t<3, 32, 8, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-        } else {
-            if (cout % 128 == 0) launch_conv2_t<1, 128, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-            else if (cout % 64 == 0) launch_conv2_t<1, 64, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-            else launch_conv2_t<1, 32, 8, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-        }
-        return;
-    }
     if (ksize == 3) {
-        if (cout % 128 == 0) launch_conv_t<3, 128>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-        else if (cout % 64 == 0) launch_conv_t<3, 64>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-        else launch_conv_t<3, 32>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        if (cout % 128 == 0) launch_conv2_t<3, 128, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        else if (cout % 64 == 0) launch_conv2_t<3, 64, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        else launch_conv2_t<3, 32, 8, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
     } else {
-        if (cout % 128 == 0) launch_conv_t<1, 128>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-        else if (cout % 64 == 0) launch_conv_t<1, 64>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-        else launch_conv_t<1, 32>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        if (cout % 128 == 0) launch_conv2_t<1, 128, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        else if (cout % 64 == 0) launch_conv2_t<1, 64, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
+        else launch_conv2_t<1, 32, 8, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
     }
 }
 
