@@ -164,7 +164,7 @@ def main():
                "avg_launch_ms": dms / max(dl, 1),
                "note": "BASELINE metric's 'HBM GB/s on conv3d': algorithmic 8 B per voxel and channel / HIP-event time"}
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
         S = args.grid + 2 * args.pad
         tm = eng.gather_tiles(vol, args.grid, p, T // 2, 1).cpu()
         ta = eng.gather_tiles(af, args.grid, p, T // 2, 1).cpu() if af is not None else None
