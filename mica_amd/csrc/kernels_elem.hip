@@ -81,26 +81,32 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
 
 // one workgroup per (tile, channel): 256 threads merge the block partials (f64 Chan merges, fixed thread->partial
 // assignment and fixed tree => deterministic)
+// Merge of the P partials f32 [B][P][C][3] = (count, mean, M2) per channel, in f64 and in a fixed order.  One block = 4
+// channels x 64 slot lanes: for a given slot the 4 channels are 48 contiguous bytes (one block per channel read its
+// 12-byte triples at a stride of C * 12 bytes: 64-B sectors for 12 useful bytes).
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ ws, int nblk, int C, float eps,
                                                              float* __restrict__ mean, float* __restrict__ rstd) {
     __shared__ double sn[256], sm[256], sq[256];
-    const int b = blockIdx.y, tid = threadIdx.x, c = blockIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cl = tid & 3, sl = tid >> 2, c = blockIdx.x * 4 + cl;
     double n = 0, m = 0, q = 0;
-    for (int k = tid; k < nblk; k += 256) {
-        const float* w = ws + (((int64_t)b * nblk + k) * C + c) * 3;
-        double nb = w[0], mb = w[1], qb = w[2];
-        if (nb > 0) {
-            double nn = n + nb, dl = mb - m;
-            m += dl * (nb / nn);
-            q += qb + dl * dl * (n * nb / nn);
-            n = nn;
+    if (c < C)
+        for (int k = sl; k < nblk; k += 64) {
+            const float* w = ws + (((int64_t)b * nblk + k) * C + c) * 3;
+            double nb = w[0], mb = w[1], qb = w[2];
+            if (nb > 0) {
+                double nn = n + nb, dl = mb - m;
+                m += dl * (nb / nn);
+                q += qb + dl * dl * (n * nb / nn);
+                n = nn;
+            }
         }
-    }
     sn[tid] = n; sm[tid] = m; sq[tid] = q;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) {
-            double nb = sn[tid + off], mb = sm[tid + off], qb = sq[tid + off];
+    for (int off = 32; off > 0; off >>= 1) {
+        if (sl < off) {
+            const int o = tid + off * 4;
+            double nb = sn[o], mb = sm[o], qb = sq[o];
             double na = sn[tid], ma = sm[tid], qa = sq[tid];
             if (nb > 0) {
                 if (na == 0) { na = nb; ma = mb; qa = qb; }
@@ -115,15 +121,15 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        mean[(int64_t)b * C + c] = (float)sm[0];
-        rstd[(int64_t)b * C + c] = (float)(1.0 / sqrt(sq[0] / sn[0] + (double)eps));
+    if (sl == 0 && c < C) {
+        mean[(int64_t)b * C + c] = (float)sm[tid];
+        rstd[(int64_t)b * C + c] = (float)(1.0 / sqrt(sq[tid] / sn[tid] + (double)eps));
     }
 }
 
 int64_t stats_ws_floats(int B, int C) { return (int64_t)B * RED_BLOCKS * C * 3; }
 void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, float* mean, float* rstd, hipStream_t st) {
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(C, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd);
 }
 // fused statistics: conv_wino writes 4 partials per 16x4x4 output tile (8 for Cout = 32), depthwise one per block
 int64_t fused_stats_ws_floats(int B, int S) {
@@ -139,7 +145,7 @@ void launch_stats(const float* x, int B, int V, int C, float eps, float* mean, f
     int G = C / 8, SUB = 256 / G;
     int nblk = pick_blocks(V, SUB * 8, RED_BLOCKS);
     hipLaunchKernelGGL(stats_kernel, dim3(nblk, B), dim3(256), 3 * 256 * 8 * sizeof(float), st, x, V, C, ws);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(C, B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd);
 }
 
 __global__ __launch_bounds__(256) void finalize_sum_kernel(const float* __restrict__ ws, int nblocks, int C, float inv,
