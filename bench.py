@@ -149,7 +149,7 @@ def main():
         if os.path.exists(tp) and B == 8 and n == 256 and not args.no_af:      # measured for exactly this workload
             traffic = json.load(open(tp)).get("kernels", {})
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_wino16_kernel (+ conv_wino_kernel for Cout 32, conv2_kernel for 1x1x1): dense 3x3x3 via Winograd F(2,3)-x, split-f16 x3 MFMA",
+        roof = {"bound": "mfma", "kernel": "conv_wino16_kernel (+ conv2_kernel for 1x1x1): dense 3x3x3 via Winograd F(2,3)-x, split-f16 x3 MFMA",
                 "achieved": ach, "peak": PEAK_SPLIT_TF, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TF,
                 "traffic": traffic.get("conv_wino16_kernel", traffic.get("conv_wino_kernel", {})).get("hbm_bytes"),
                 "launches_per_batch": launches, "avg_launch_ms": ms / max(launches, 1),

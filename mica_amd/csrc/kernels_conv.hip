@@ -555,14 +555,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                                                              int ntx, int nty, int nnb, int items_per_b, int total_items,
                                                              float* __restrict__ stats_ws) {
     using G = GeoW;
-    static_assert(BN == 128 || BN == 64, "two variants");
+    static_assert(BN == 128 || BN == 64 || BN == 32, "three variants");
     // BN = 128: the two wave groups (wn) own 64 output channels each and walk all 14 steps of a chunk.
     // BN = 64 : both groups own the same 64 channels and SPLIT THE TAPS, 7 steps each (group 0: taps 0..4 less the X terms of
     //           tap 4/5, group 1: the rest); the per-wave tile, operand reuse and weight traffic per MFMA stay those of the
     //           128 variant, and the two partial accumulators are added through LDS before the output transform.
-    constexpr bool SPLIT = BN == 64;
+    // BN = 32 : as BN = 64 with two column tiles per wave instead of four (an A fragment then feeds two MFMAs; LDS has room).
+    constexpr bool SPLIT = BN <= 64;
     constexpr int NS = SPLIT ? 7 : 14;              // steps per wave and chunk
-    constexpr int WNC = 64;
+    constexpr int WNC = BN == 32 ? 32 : 64;         // output channels per wave
+    constexpr int NCT = WNC / 16;                   // column tiles (and weight fragments per step) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -598,22 +600,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
     const int64_t nbstride = (int64_t)total_chunks * chstride;
     const char* wwave = reinterpret_cast<const char*>(wpk) + wp * 8 * ustride + (SPLIT ? 0 : wn * WNC * 16);
 
-    half8 bq[3][4];          // weight fragment sets; the third only when NS is odd (see W16_SET)
+    half8 bq[3][NCT];        // weight fragment sets; the third only when NS is odd (see W16_SET)
     // step parameters: global step st (0..13) -> scalars; a wave's local step ls is global step ls (+ 7 for group 1 of BN = 64)
 #define W16_TAP(st) (2 * w16_step_ps(st) + (w16_step_kind(st) == 1 ? 1 : 0))
 #define W16_AOFF(st) (((W16_TAP(st) / 3) * G::PZ + (W16_TAP(st) % 3) * 8) * 16)
 #define W16_ADELTA(st) (w16_step_kind(st) != 0 ? 2 * G::PLANE * 16 : (w16_step_ps(st) == 1 ? (G::PZ - 16) * 16 : 8 * 16))
 #define W16_WOFF(st) (w16_step_ps(st) * psstride + (w16_step_kind(st) == 0 ? 4 : w16_step_kind(st) == 1 ? 2 : 0) * ustride)
 #define W16_WDELTA(st) (w16_step_kind(st) == 0 ? 2 * BN * 16 : 0)
-#define W16_SEL(ls, M) ((SPLIT && wn == 1) ? M((ls) + 7) : M(ls))
+#define W16_SEL(ls, M) ((SPLIT && wsel == 1) ? M((ls) + 7) : M(ls))
 #define MICA_BLOAD16(set, wbase, ls)                                                                                    \
     do {                                                                                                                \
         const char* pb_ = (wbase) + W16_SEL(ls, W16_WOFF);                                                              \
         const unsigned vo_ = w_common + (unsigned)(W16_SEL(ls, W16_WDELTA) & himask);                                   \
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][0]) : "v"(vo_), "s"(pb_) : "memory");              \
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(bq[set][1]) : "v"(vo_), "s"(pb_) : "memory");   \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(bq[set][2]) : "v"(vo_), "s"(pb_) : "memory");   \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:768" : "=v"(bq[set][3]) : "v"(vo_), "s"(pb_) : "memory");   \
+        if (NCT == 4) {                                                                                                 \
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(bq[set][NCT - 2]) : "v"(vo_), "s"(pb_) : "memory"); \
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:768" : "=v"(bq[set][NCT - 1]) : "v"(vo_), "s"(pb_) : "memory"); \
+        }                                                                                                               \
     } while (0)
     // One slab DMA instruction: issued UNCONDITIONALLY (lanes outside the volume are masked off by hand and write an explicit
     // zero instead) so that the number of vector-memory operations in flight is known at compile time: the weight waits can
@@ -691,6 +695,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 #define W16_XHI(ls) (((SPLIT ? 0x1B : 0x16DB) >> (ls)) & 1)
 #define W16_DMA0(ls) (SPLIT ? ((ls) < 3 ? 2 * (ls) : (ls) + 3) : (ls))
     // prologue of the first item: slab chunk 0 -> buffer 0, weights of the wave's first step
+    int wsel = wn;
     MICA_BLOAD16(W16_SET(0), cur.w, 0);
 #pragma unroll
     for (int k = 0; k < G::DPW; ++k) MICA_SLAB_DMA(cur.src0, 0, k, cur);
@@ -700,11 +705,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 
     for (;;) {
         const bool has_next = nitem < it_end;
-        floatx4v acc[8][4];
+        floatx4v acc[8][NCT];
 #pragma unroll
         for (int f = 0; f < 8; ++f)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < NCT; ++c)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[f][c][i] = 0.f;
 
@@ -712,10 +717,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
         const _Float16* run = cur.src0;
         int si = 0, left = s.chunks[0];
         const char* wcur = cur.w;
+#pragma clang loop unroll(disable)      // also keeps the first iteration from being peeled into a second copy of the body
         for (int gch = 0; gch < total_chunks; ++gch) {
             const char* A = smem + par * G::CH_BYTES;
             const int nxt_off = (par ^ 1) * G::CH_BYTES;
             const bool last = gch + 1 == total_chunks;
+            // the group selector is laundered per chunk: as a loop invariant it invites the compiler to clone the whole chunk
+            // body per group, and the audit of the hand-waited loads (tools/audit_asm_loads.py) reads straight-line code
+            wsel = wn;
+            asm volatile("" : "+s"(wsel));
             if (!last) {
                 if (--left == 0) {
                     ++si;
@@ -742,14 +752,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
             half8 a0 = W16_AFRAG(ab_cur, 0), a1 = W16_AFRAG(ab_cur, 1), a2 = W16_AFRAG(ab_cur, 2), a3;
 #pragma unroll
             for (int ls = 0; ls < NS; ++ls) {
-                half8 (&bc)[4] = bq[W16_SET(ls)];
+                half8 (&bc)[NCT] = bq[W16_SET(ls)];
                 if (ls + 1 < NS) MICA_BLOAD16(W16_SET(ls + 1), wcur, ls + 1);
                 else MICA_BLOAD16(W16_SET(0), wnxt, 0);
-                const int newer = 4 + (ls >= 1 ? W16_NDMA(ls - 1) : 0);
-                if (newer == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
-                else if (newer == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
-                else asm volatile("s_waitcnt vmcnt(6)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
-                static_assert(W16_NDMA(0) <= 2, "wait immediates above: 4, 5 or 6 newer operations");
+                // in flight and NEWER than this step's fragments: the NCT loads just issued plus the previous step's slab DMAs
+                const int newer = NCT + (ls >= 1 ? W16_NDMA(ls - 1) : 0);
+#define W16_WAIT(N) do { if (NCT == 4) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[NCT - 2]), "+v"(bc[NCT - 1])); \
+                         else asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bc[0]), "+v"(bc[1])); } while (0)
+                if (newer == 2) W16_WAIT(2);
+                else if (newer == 3) W16_WAIT(3);
+                else if (newer == 4) W16_WAIT(4);
+                else if (newer == 5) W16_WAIT(5);
+                else W16_WAIT(6);
+#undef W16_WAIT
+                static_assert(W16_NDMA(0) <= 2, "wait immediates above: NCT + 0..2 newer operations");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < W16_NDMA(ls); ++q) MICA_SLAB_DMA(nsrc, nxt_off, W16_DMA0(ls) + q, org);
@@ -772,7 +788,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                     if (f + 3 < 8) a3 = W16_AFRAG(ab_cur, f + 3);
                     else if (ls + 1 < NS) a3 = W16_AFRAG(ab_nxt, f + 3 - 8);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                    for (int c = 0; c < NCT; ++c)
                         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(a0), "v"(bc[c]));
                     __builtin_amdgcn_sched_barrier(0);
                     a0 = a1;
@@ -783,13 +799,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
             }
 #undef W16_ABASE
 #undef W16_AFRAG
-            // the slab DMAs of this chunk are older than the four weight loads still wanted in flight
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // the slab DMAs of this chunk are older than the NCT weight loads still wanted in flight
+            if (NCT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __syncthreads();
             par ^= 1;
             wcur = wnxt;
         }
         asm volatile("s_setprio 0");
+        // the next item's first weight fragments were requested a step ago: retire them here, so that the compiler may
+        // move their registers freely through the epilogue and the loop back edge (it cannot see that they were in flight)
+        if (NCT == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[W16_SET(0)][0]), "+v"(bq[W16_SET(0)][1]), "+v"(bq[W16_SET(0)][NCT - 2]), "+v"(bq[W16_SET(0)][NCT - 1]));
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[W16_SET(0)][0]), "+v"(bq[W16_SET(0)][1]));
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU/LDS readers: the hazard the compiler cannot see through the asm
 
         // ---- output transform through the idle slab buffer (the other one already holds the next item's first chunk) ----
@@ -813,7 +834,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
             const int frow = lane / CG, fcg = lane % CG;
             const int P = (items_per_b / nnb) * 4;
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
+            for (int pass = 0; pass < (SPLIT ? NCT : 4); ++pass) {
                 const int c0 = SPLIT ? pass : (pass >> 1) * 2;       // first column tile of the pass
                 const int wq = SPLIT ? 0 : (pass & 1);               // the group that writes T
                 if (SPLIT) {
@@ -934,7 +955,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 #undef MICA_BLOAD16
 #undef MICA_SLAB_DMA
     // nothing may still be in flight towards this workgroup's registers or LDS when it ends
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[W16_SET(0)][0]), "+v"(bq[W16_SET(0)][1]), "+v"(bq[W16_SET(0)][2]), "+v"(bq[W16_SET(0)][3]));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[W16_SET(0)][0]), "+v"(bq[W16_SET(0)][1]), "+v"(bq[W16_SET(0)][NCT - 2]), "+v"(bq[W16_SET(0)][NCT - 1]));
 #undef W16_SET
 #undef W16_NDMA
 #undef W16_DMA0
@@ -947,7 +968,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 #undef W16_SEL
 }
 
-// which layers take conv_wino16: Cout a multiple of 64 (block of 128 channels when possible, else 64); MICA_W16=0 (development)
+// which layers take conv_wino16: every Cout (a multiple of 32: blocks of 128 channels when possible, else 64, else 32); MICA_W16=0 (development)
 // sends everything back to conv_wino_kernel
 static int wino16_block(int cout) {
     static int v = -1;
@@ -957,7 +978,8 @@ static int wino16_block(int cout) {
     }
     if (v == 0) return 0;
     if (cout % 128 == 0) return 128;
-    return (v == 1 && cout % 64 == 0) ? 64 : 0;
+    if (v != 1) return 0;
+    return cout % 64 == 0 ? 64 : (cout % 32 == 0 ? 32 : 0);
 }
 
 static int launch_conv_wino16(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
@@ -971,6 +993,7 @@ static int launch_conv_wino16(const ConvSrcs& s, const _Float16* wpk, int64_t wp
     if (!cus) {
         (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
@@ -983,8 +1006,11 @@ static int launch_conv_wino16(const ConvSrcs& s, const _Float16* wpk, int64_t wp
     if (bn == 128)
         hipLaunchKernelGGL((conv_wino16_kernel<128>), dim3(nwg), dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
                            cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws);
-    else
+    else if (bn == 64)
         hipLaunchKernelGGL((conv_wino16_kernel<64>), dim3(nwg), dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
+                           cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws);
+    else
+        hipLaunchKernelGGL((conv_wino16_kernel<32>), dim3(nwg), dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
                            cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws);
     return ntx * nty * ntz * 4;
 }

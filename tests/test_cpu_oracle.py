@@ -212,8 +212,9 @@ def test_inline_asm_weight_prefetch_is_hazard_free(tmp_path):
     assert found == 3
     # the persistent 16x16x32 variants: same audit with their LDS-DMA instructions occupying queue slots.  Per chunk and wave the
     # 128-channel variant walks 14 steps (448 MFMAs; 9 waits that leave the previous step's one DMA in flight, 5 + 1 plain
-    # ones), the 64-channel variant 7 steps (224 MFMAs; previous step issued 2, 1 or 0 DMAs); one copy of the chunk body each
-    for bn, n_mfma, waits in ((128, 448, {5: 9, 4: 6}), (64, 224, {6: 3, 5: 3, 4: 2})):
+    # ones), the 64-channel variant 7 steps (224 MFMAs; previous step issued 2, 1 or 0 DMAs), the 32-channel variant 7 steps of
+    # two column tiles (112 MFMAs, two weight loads per step); one copy of the chunk body each
+    for bn, n_mfma, waits in ((128, 448, {5: 9, 4: 6}), (64, 224, {6: 3, 5: 3, 4: 2}), (32, 112, {4: 3, 3: 3, 2: 2})):
         m = re.search(r"^_ZN4mica18conv_wino16_kernelILi%dE.*?s_endpgm" % bn, text, flags=re.S | re.M)
         assert m, bn
         part = str(tmp_path / ("wino16_%d.s" % bn))

@@ -35,7 +35,7 @@ def _rand(shape, seed, lo=-1.0, hi=1.0):
 @pytest.mark.parametrize("cin,cout,k,dims", [
     (16, 32, 3, (8, 8, 8)), (24, 64, 3, (8, 8, 16)), (64, 128, 3, (6, 10, 20)), (196, 64, 3, (8, 8, 8)),
     (96, 32, 3, (16, 16, 16)), (128, 64, 1, (8, 8, 8)), (192, 64, 1, (4, 12, 9)), (512, 256, 1, (8, 8, 8)),
-    (32, 256, 3, (8, 8, 8)), (40, 128, 3, (5, 7, 9)), (144, 256, 3, (12, 6, 18)), (48, 192, 3, (6, 9, 14)),     # 64-multiples: the persistent 16x16x32 variants
+    (32, 256, 3, (8, 8, 8)), (40, 128, 3, (5, 7, 9)), (144, 256, 3, (12, 6, 18)), (48, 192, 3, (6, 9, 14)), (40, 96, 3, (7, 9, 12)),     # 128 / 64 / 32 blocks of the persistent 16x16x32 conv
 ])
 def test_conv3d(eng, cin, cout, k, dims):
     x = _rand((2, cin, *dims), 1)
