@@ -46,6 +46,24 @@ def test_conv3d(eng, cin, cout, k, dims):
     assert rel_err(got, ref) < RTOL
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_conv3d_persistent_schedule_odd_shapes(eng, seed):
+    """The persistent conv distributes (batch, tile, channel block) items over one workgroup per CU: item counts below,
+    equal to and not divisible by the number of workgroups, single-chunk layers (Cin <= 16), ragged volumes whose
+    tiles hang over every face, the blocked and the linear tile walk (nty % 8, ntz % 4)."""
+    rng = np.random.default_rng(100 + seed)
+    cin = int(rng.choice([3, 16, 24, 40, 72, 130]))
+    cout = int(rng.choice([32, 64, 96, 128, 160, 192, 256]))
+    dims = [(5, 6, 7), (4, 4, 34), (17, 3, 5), (16, 32, 16), (9, 33, 18), (3, 64, 64), (20, 8, 40), (1, 1, 1)][seed]
+    batch = int(rng.integers(1, 4))
+    x = _rand((batch, cin, *dims), 200 + seed)
+    w = _rand((cout, cin, 3, 3, 3), 300 + seed) * (3.0 / (cin * 27)) ** 0.5
+    b = _rand((cout,), 400 + seed) * 0.1
+    ref = F.conv3d(x, w, b, padding=1)
+    got = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3)
+    assert rel_err(got, ref) < RTOL
+
+
 def test_conv3d_asymmetric_identity(eng):
     """A = delta input, asymmetric weights: catches transposed MFMA operand / C-D maps."""
     x = torch.zeros((1, 16, 8, 8, 16))
