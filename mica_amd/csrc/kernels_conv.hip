@@ -749,7 +749,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 #define W16_ABASE(ls) (A + a_common + (W16_SEL(ls, W16_ADELTA) & himask) + W16_SEL(ls, W16_AOFF))
 #define W16_AFRAG(base, f) (*reinterpret_cast<const half8*>((base) + ((((f) >> 1) * G::PZ + ((f) & 1) * 16) * 16)))
             const char* ab_cur = W16_ABASE(0);
-            half8 a0 = W16_AFRAG(ab_cur, 0), a1 = W16_AFRAG(ab_cur, 1), a2 = W16_AFRAG(ab_cur, 2), a3;
+            // AD fragments ahead: 3 groups of four MFMAs, or 6 groups of two (BN = 32), cover the LDS latency
+            constexpr int AD = NCT == 4 ? 3 : 6;
+            half8 ar[AD + 1];
+#pragma unroll
+            for (int i = 0; i < AD; ++i) ar[i] = W16_AFRAG(ab_cur, i);
 #pragma unroll
             for (int ls = 0; ls < NS; ++ls) {
                 half8 (&bc)[NCT] = bq[W16_SET(ls)];
@@ -785,15 +789,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                             asm volatile("s_setprio 1");
                         }
                     }
-                    if (f + 3 < 8) a3 = W16_AFRAG(ab_cur, f + 3);
-                    else if (ls + 1 < NS) a3 = W16_AFRAG(ab_nxt, f + 3 - 8);
+                    const int fi = ls * 8 + f;                  // fragment index within the chunk; lives in ar[fi % (AD + 1)]
+                    if (f + AD < 8) ar[(fi + AD) % (AD + 1)] = W16_AFRAG(ab_cur, f + AD);
+                    else if (ls + 1 < NS) ar[(fi + AD) % (AD + 1)] = W16_AFRAG(ab_nxt, f + AD - 8);
 #pragma unroll
                     for (int c = 0; c < NCT; ++c)
-                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(a0), "v"(bc[c]));
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(ar[fi % (AD + 1)]), "v"(bc[c]));
                     __builtin_amdgcn_sched_barrier(0);
-                    a0 = a1;
-                    a1 = a2;
-                    a2 = a3;
                 }
                 ab_cur = ab_nxt;
             }
