@@ -61,19 +61,23 @@ class VolumePredictor:
                 "amino_acid_prediction": out[2], "amino_acid_probability": out[3:]}
 
     def predict_maps_streamed(self, maps, afs=None):
-        """Several independent maps back to back (BASELINE.json configs[4]): host arrays are staged through two
-        pinned buffers and uploaded with hipMemcpyAsync on a copy stream while the previous map computes
-        (double-buffered H2D); results come back as dicts of host arrays.  `maps`: list of float32 [N0,N1,N2]
-        numpy arrays, `afs`: optional list of float32 [24,N0,N1,N2] (or None entries)."""
+        """Several independent maps back to back (BASELINE.json configs[4]) with host buffers on both sides.
+        Map i+1 is staged (host copy into pinned memory on a helper thread, then hipMemcpyAsync on a copy stream) while
+        map i computes; the four volumes of map i travel back through a pinned buffer on the copy stream while map i+1
+        computes.  `maps`: list of float32 [N0,N1,N2] numpy arrays, `afs`: optional list of float32 [24,N0,N1,N2] (or
+        None entries); returns a list of dicts of host arrays."""
+        import threading
+
         import numpy as np
         e = self.e
         dev = e.device
         copy_stream = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
         afs = afs or [None] * len(maps)
-        slots = [None, None]          # (pinned map, pinned af, device map, device af, ready event)
+        slots = [None, None]          # per parity: (pinned map, pinned af, device map, device af, ready event)
 
         def stage(i):
+            torch.cuda.set_device(dev)
             m = np.ascontiguousarray(maps[i], dtype=np.float32)
             a = None if afs[i] is None else np.ascontiguousarray(afs[i], dtype=np.float32)
             k = i & 1
@@ -92,22 +96,54 @@ class VolumePredictor:
                 ev.record(copy_stream)
             slots[k] = (pm, pa, dm, da, ev)
 
-        results = []
+        def collect(pending):
+            """finish the download of a previous map: (pinned [23,...] buffer, event) -> dict of host arrays"""
+            buf, ev = pending
+            ev.synchronize()
+            h = buf.numpy()
+            return {"backbone_probability": h[0].copy(), "carbon_alpha_probability": h[1].copy(),
+                    "amino_acid_prediction": h[2].copy(), "amino_acid_probability": h[3:].copy()}
+
+        results, pending = [None] * len(maps), None
+        hbuf = [None, None]           # pinned download buffers, by parity
+
+        def helper(i, pend):
+            """runs beside map i's compute: stage map i+1, unpack map i-1"""
+            if i + 1 < len(maps):
+                stage(i + 1)
+            if pend is not None:
+                results[i - 1] = collect(pend)
+
         if maps:
             stage(0)
         for i in range(len(maps)):
             pm, pa, dm, da, ev = slots[i & 1]
-            if i + 1 < len(maps):
-                # the other slot's previous tensors were consumed by map i-1, whose kernels are already enqueued on
-                # `main`; make the copy stream wait for them before the buffers are overwritten
-                copy_stream.wait_stream(main)
-                stage(i + 1)
+            # the other slot's device tensors were consumed by map i-1, whose kernels are already enqueued on `main`;
+            # the copy stream waits for them before the buffers are overwritten
+            copy_stream.wait_stream(main)
+            th = threading.Thread(target=helper, args=(i, pending))
+            th.start()
             main.wait_event(ev)
             dm.record_stream(main)
             if da is not None:
                 da.record_stream(main)
-            out = self.predict_volume(dm, da)
-            results.append({k: v.cpu().numpy() for k, v in out.items()})
+            out = self.predict_volume(dm, da)                      # dict of views of one [23, N0, N1, N2] tensor
+            full = out["backbone_probability"]._base
+            done = torch.cuda.Event()
+            done.record(main)
+            th.join()                                              # map i-1 is unpacked: its pinned buffer (other parity) is free
+            k = i & 1
+            if hbuf[k] is None or hbuf[k].shape != full.shape:
+                hbuf[k] = torch.empty(full.shape, dtype=torch.float32, pin_memory=True)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done)
+                hbuf[k].copy_(full, non_blocking=True)
+                full.record_stream(copy_stream)
+                dl = torch.cuda.Event()
+                dl.record(copy_stream)
+            pending = (hbuf[k], dl)
+        if pending is not None:
+            results[len(maps) - 1] = collect(pending)
         return results
 
     def predict_volume_sharded(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None, group=None):
