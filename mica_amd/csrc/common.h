@@ -92,7 +92,7 @@ void launch_feat_gate(const float* x, int B, int V, const float* w0, const float
 void launch_head_final(const float* x, int B, int V, const float* mean, const float* rstd, const float* gate,
                        const float* wf, const float* bf, int ncls, float* logits, SplitView extra,
                        int extra_ch_off, float* extra_raw, int extra_raw_c, hipStream_t st);
-// ---- Winograd F(2,3) along x (dense 3^3 convs): operand layout [B][chunks][4][Vh][2][16], Vh = D*H*ceil(W/2)
+// ---- Winograd F(2,3) along x (dense 3^3 convs): operand layout [B][chunks][4 p][4 q][Vh][8], Vh = D*H*ceil(W/2)
 void launch_prep_wino(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, int relu,
                       const float* scale, SplitView wino, SplitView plain, float* gap, float* ws, int* errflag,
                       hipStream_t st);

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvSrcs s, const _Fl
         const int vy = r2 >> 3, pr = r2 & 7;
         const int gi = i0 + pr, gy = y0 + vy, gz = z0 + vz;
         const bool ok = gi < Wh && (unsigned)gy < (unsigned)d.H && (unsigned)gz < (unsigned)d.D;
-        goff[k] = ok ? (pp * Vh + (gz * d.H + gy) * Wh + gi) * 32 + q * 8 : -1;
+        goff[k] = ok ? ((pp * 4 + q) * Vh + (gz * d.H + gy) * Wh + gi) * 8 : -1;
         loff[k] = (q * G::PLANE + vz * G::PZ + part * 64) * 16;
     }
 
@@ -532,7 +532,7 @@ __device__ __forceinline__ int w16_slab_rel(int wave, int lane, int k, int H, in
     const int slot = part * 64 + lane;
     const int pp = slot / GeoW::PP, r2 = slot - pp * GeoW::PP;
     const int vy = r2 >> 3, pr = r2 & 7;          // pr == lane & 7 for every k
-    return ((pp * Vh + (vz * H + vy) * Wh + pr) * 32 + q * 8) * 2 + vy;
+    return (((pp * 4 + q) * Vh + (vz * H + vy) * Wh + pr) * 8) * 2 + vy;
 }
 __device__ __forceinline__ int w16_slab_vz(int wave, int k) { return ((wave * GeoW::DPW + k) % (GeoW::SZ * GeoW::DPZ)) / GeoW::DPZ; }
 // Chan's pairwise merge of (count, mean, M2)
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
         r.i0 = tx * 8;
         r.y0 = ty * 4 - 1;
         r.z0 = tz * 4 - 1;
-        r.base = ((r.z0 * d.H + r.y0) * Wh + r.i0) * 64;
+        r.base = ((r.z0 * d.H + r.y0) * Wh + r.i0) * 16;
         r.w = wwave + (int64_t)r.b * wpk_bstride * 2 + r.nb * nbstride;
         r.src0 = chunk_base_wino(s, 0, r.b, Vh);
         return r;

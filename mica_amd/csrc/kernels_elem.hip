@@ -265,7 +265,10 @@ void launch_prep(const float* x, int B, int V, int C, const float* mean, const f
 // prep for Winograd F(2,3) convs: the same y = relu?((x-mean)*rstd)*scale, written as the x-direction
 // input transform of each output pair (x = 2i, 2i+1):  with d_k = y(2i-1+k), zero outside the volume,
 //   t0 = d0 - d2,  t1 = d1 + d2,  t2 = d2 - d1,  t3 = d1 - d3
-// in "wino" layout  _Float16 [B][chunks][4 (p)][Vh][2][16],  Vh = D*H*ceil(W/2)  (2x the plain bytes).
+// in "wino" layout  _Float16 [B][chunks][4 (p)][4 (q)][Vh][8],  Vh = D*H*ceil(W/2)  (2x the plain bytes); q = hi|lo x channel
+// half of the chunk.  Sixteen planes of 16-byte pieces per chunk: consecutive pairs are consecutive 16-byte pieces, so
+// this kernel's stores and the conv's slab DMA both move whole 128-byte lines per instruction (with 64-byte
+// [hi 16 | lo 16] records per pair an instruction touched a quarter to a half of every line it named).
 // Thread = (8-channel group, pair); its own voxels are d1, d2 (plain / raw / gap outputs use those).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict__ x, Dims d, int C,
@@ -292,7 +295,8 @@ __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict_
     }
     bool bad = false;
     const float* xb = x + (int64_t)b * V * C + g * 8;
-    _Float16* wb = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + (g >> 1)) * 4 * Vh) * 32 + (g & 1) * 8;
+    _Float16* wb = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + (g >> 1)) * 4 * Vh) * 32;
+    const int kh = g & 1;                           // which 8 of the chunk's 16 channels: plane q = kh (hi), 2 + kh (lo)
     _Float16* pb = plain.p ? plain.p + (((int64_t)b * plain.chunks_total + plain.chunk_off + (g >> 1)) * V) * 32 + (g & 1) * 8 : nullptr;
     for (int ph = p0 + sub; ph < p1; ph += SUB) {
         const int row = ph / Wh, i = ph - row * Wh;
@@ -326,9 +330,8 @@ __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict_
         for (int pp = 0; pp < 4; ++pp) {
             half8 hi, lo;
             split8(t[pp], hi, lo, bad);
-            _Float16* o = wb + ((int64_t)pp * Vh + ph) * 32;
-            *reinterpret_cast<half8*>(o) = hi;
-            *reinterpret_cast<half8*>(o + 16) = lo;
+            *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + kh) * Vh + ph) * 8) = hi;
+            *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 2 + kh) * Vh + ph) * 8) = lo;
         }
         if (pb) {
 #pragma unroll
@@ -396,17 +399,16 @@ __global__ __launch_bounds__(256) void prep_ncdhw_wino_kernel(const float* __res
     _Float16* wb = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + ch) * 4 * Vh) * 32;
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
-        _Float16* o = wb + ((int64_t)pp * Vh + ph) * 32;
         float y0[8], y1[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { y0[j] = t[pp][j]; y1[j] = t[pp][8 + j]; }
         half8 hi, lo;
         split8(y0, hi, lo, bad);
-        *reinterpret_cast<half8*>(o) = hi;
-        *reinterpret_cast<half8*>(o + 16) = lo;
+        *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 0) * Vh + ph) * 8) = hi;
+        *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 2) * Vh + ph) * 8) = lo;
         split8(y1, hi, lo, bad);
-        *reinterpret_cast<half8*>(o + 8) = hi;
-        *reinterpret_cast<half8*>(o + 24) = lo;
+        *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 1) * Vh + ph) * 8) = hi;
+        *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 3) * Vh + ph) * 8) = lo;
     }
     if (bad) atomicOr(errflag, 1);
 }
