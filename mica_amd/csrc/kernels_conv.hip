@@ -14,6 +14,16 @@ namespace mica {
 
 struct Segs { int c[MAX_SRC]; int cp[MAX_SRC]; int n; };   // channel segmentation of a conv's concatenated input
 
+// "once per device" guard for hipFuncSetAttribute (one process normally drives one GPU, but an Engine per device in one
+// process must work too: the dynamic-LDS limit of a kernel is a per-device attribute)
+static bool first_use_on_device(unsigned long long& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    const bool first = !(mask >> dev & 1ull);
+    mask |= 1ull << dev;
+    return first;
+}
+
 // ================================================================================================
 // conv2 (direct conv; now the 1x1x1 convs and the MICA_WINO=0 fallback): structured around the measured stalls of the
 // first version (four-wave workgroups staging A and B through LDS per tap: 57 % of the wave-cycles waited at the per-tap
@@ -231,11 +241,9 @@ static void launch_conv2_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_b
     for (int i = 0; i < s.n; ++i) total += s.chunks[i];
     int ntx = (d.W + 15) / 16, nty = (d.H + 7) / 8, ntz = (d.D + 3) / 4, nnb = cout / BN;
     size_t lds = 2 * G::STAGE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long seen = 0;
+    if (first_use_on_device(seen))
         (void)hipFuncSetAttribute((const void*)conv2_kernel<KS, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     dim3 grid(ntx * nty * ntz * nnb, B);
     hipLaunchKernelGGL((conv2_kernel<KS, BN, WM, WN>), grid, dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
                        cout, total, ntx, nty, nnb);
@@ -991,17 +999,22 @@ static int launch_conv_wino16(const ConvSrcs& s, const _Float16* wpk, int64_t wp
     const int bn = wino16_block(cout);
     int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / bn;
     size_t lds = 2 * GeoW::CH_BYTES;
-    static int cus = 0;
-    if (!cus) {
+    static unsigned long long seen = 0;
+    static int cus_of[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev > 63) dev = 0;
+    if (first_use_on_device(seen)) {
         (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus < 8) cus = 256;
-        cus &= ~7;
+        int c = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+        if (c < 8) c = 256;
+        cus_of[dev] = c & ~7;
     }
+    const int cus = cus_of[dev];
     // one persistent workgroup per CU (LDS admits no more), a multiple of eight so that every XCD gets the same number
     const int items_per_b = ntx * nty * ntz * nnb, total_items = items_per_b * B;
     const int nwg = total_items >= cus ? cus : ((total_items + 7) / 8) * 8;
@@ -1024,11 +1037,9 @@ static int launch_conv_wino_t(const ConvSrcs& s, const _Float16* wpk, int64_t wp
     for (int i = 0; i < s.n; ++i) total += s.chunks[i];
     int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / BN;
     size_t lds = 2 * GeoW::CH_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long seen = 0;
+    if (first_use_on_device(seen))
         (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     dim3 grid(ntx * nty * ntz * nnb, B);
     hipLaunchKernelGGL((conv_wino_kernel<BN, WN>), grid, dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout,
                        total, ntx, nty, nnb, stats_ws);
@@ -1433,11 +1444,9 @@ static void launch_depthwise_t(const float* x, int B, Dims d, int C, const float
                                const float* w27, const float* bias, float* out, float* stats_ws, int ntx, int nty, hipStream_t st) {
     using Gm = DwGeo<YO, CQ>;
     const size_t lds = (3 * Gm::PLANE + 27 * Gm::DWC) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long seen = 0;
+    if (first_use_on_device(seen))
         (void)hipFuncSetAttribute((const void*)depthwise_kernel<YO, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
     dim3 grid((unsigned)(ntx * nty * (C / Gm::DWC)), B);
     hipLaunchKernelGGL((depthwise_kernel<YO, CQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty);
 }
