@@ -112,6 +112,25 @@ int mica_zoom_cubic(mica_ctx* ctx, const float* d_in, int64_t n0, int64_t n1, in
 int mica_rasterise_atoms(mica_ctx* ctx, const float* d_xyz, const int32_t* d_bb, const int32_t* d_aa, int64_t n_atoms,
                          const float* h_origin, int64_t nz, int64_t ny, int64_t nx, float* d_vol, void* stream);
 
+/* ---- point lists for the consumer of the volumes: Solver.clustering (utils/modeler.py:762-858) ---------------- */
+/* The three steps of it that touch whole volumes, so that only the candidate points leave the GPU.  DBSCAN (open3d,
+ * :770), the cluster scores and the greedy non-maximum suppression (:822-831) work on the point list and stay with the
+ * caller.
+ * np.array(np.where(vol > thr)).T (:767) as ascending linear indices into d_vol f32[n] (= lexicographic (x, y, z) order);
+ * writes at most `capacity` of them, *h_count = how many there are.  Synchronous.                                  */
+int mica_threshold_points(mica_ctx* ctx, const float* d_vol, int64_t n, float thr, int64_t* d_idx, int64_t capacity,
+                          int64_t* h_count, void* stream);
+/* d_out f32[channels][n] = d_vol f32[channels][nvox] at linear indices d_idx (:780, :786, :800, :856, :884); MICA_ERR_ARG
+ * if an index is outside [0, nvox).  Synchronous.                                                                  */
+int mica_gather_values(mica_ctx* ctx, const float* d_vol, int channels, int64_t nvox, const int64_t* d_idx, int64_t n,
+                       float* d_out, void* stream);
+/* Candidate refinement (:836-852): d_cand int32[n][3] voxel positions -> d_coord f64[n][3] (CAProb-weighted mean over the
+ * 3x3x3 neighbourhood), d_aa_out f32[n][20] (the same weights on d_aa f32[20][n0][n1][n2]), d_ok int32[n] = 0 where the
+ * reference skips the candidate ("found at boundary": a coordinate equal to 0 or n-1).  numpy's arithmetic operation by
+ * operation (float32 weights and amino-acid sums, float64 positions, numpy's pairwise order for the 27-voxel sum).     */
+int mica_refine_candidates(mica_ctx* ctx, const float* d_ca, const float* d_aa, int64_t n0, int64_t n1, int64_t n2,
+                           const int32_t* d_cand, int64_t n, double* d_coord, float* d_aa_out, int32_t* d_ok, void* stream);
+
 /* ---- single-op entry points (parity tests drive each kernel through the ABI) -------------- */
 /* Conv3d k in {1,3}, stride 1, 'same' zero padding, on the split-f16 MFMA path.
  * d_x f32[B][Cin][D][H][W] NCDHW, h_w f32[Cout][Cin][k][k][k], h_b f32[Cout] -> d_y f32[B][Cout][D][H][W]. */

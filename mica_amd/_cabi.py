@@ -37,6 +37,9 @@ SIGNATURES = {
     "mica_normalise_map": (_I, [_P, _P, _L, _DP, _P]),
     "mica_zoom_cubic": (_I, [_P, _P, _L, _L, _L, _L, _L, _L, _P, _P]),
     "mica_rasterise_atoms": (_I, [_P, _P, _P, _P, _L, _FP, _L, _L, _L, _P, _P]),
+    "mica_threshold_points": (_I, [_P, _P, _L, _F, _P, _L, _LP, _P]),
+    "mica_gather_values": (_I, [_P, _P, _I, _L, _P, _L, _P, _P]),
+    "mica_refine_candidates": (_I, [_P, _P, _P, _L, _L, _L, _P, _L, _P, _P, _P, _P]),
     "mica_op_conv3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _I, _P, _P]),
     "mica_op_instnorm_relu": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mica_op_depthwise3": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _P, _P]),

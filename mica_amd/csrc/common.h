@@ -121,4 +121,12 @@ int zoom_cubic_device(const float* d_in, int64_t n0, int64_t n1, int64_t n2, int
 int rasterise_atoms_device(const float* d_xyz, const int* d_bb, const int* d_aa, int64_t n_atoms, const float* origin, int64_t nz,
                            int64_t ny, int64_t nx, float* d_vol, hipStream_t st, char* err, int errlen);
 
+// point-list kernels (kernels_points.hip; modeler.py:767, 836-852) ; threshold and gather are synchronous
+int threshold_points_device(const float* d_vol, int64_t n, float thr, int64_t* d_idx, int64_t capacity, int64_t* h_count, hipStream_t st,
+                            char* err, int errlen);
+int gather_values_device(const float* d_vol, int C, int64_t nvox, const int64_t* d_idx, int64_t n, float* d_out, hipStream_t st, char* err,
+                         int errlen);
+int refine_candidates_device(const float* d_ca, const float* d_aa, int n0, int n1, int n2, const int* d_cand, int64_t n, double* d_coord,
+                             float* d_aa_out, int* d_ok, hipStream_t st, char* err, int errlen);
+
 }  // namespace mica

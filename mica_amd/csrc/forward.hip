@@ -771,6 +771,50 @@ int mica_rasterise_atoms(mica_ctx* c, const float* d_xyz, const int32_t* d_bb, c
     return r;
 }
 
+int mica_threshold_points(mica_ctx* c, const float* d_vol, int64_t n, float thr, int64_t* d_idx, int64_t capacity, int64_t* h_count,
+                          void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_vol || n < 1 || n > ((int64_t)1 << 36) || capacity < 0 || (capacity > 0 && !d_idx) || !h_count) {
+        c->err = "mica_threshold_points: bad argument";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    char buf[256] = {0};
+    int r = threshold_points_device(d_vol, n, thr, d_idx, capacity, h_count, (hipStream_t)stream, buf, sizeof(buf));
+    if (r) c->err = buf;
+    return r;
+}
+
+int mica_gather_values(mica_ctx* c, const float* d_vol, int channels, int64_t nvox, const int64_t* d_idx, int64_t n, float* d_out,
+                       void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_vol || channels < 1 || nvox < 1 || n < 0 || (n > 0 && (!d_idx || !d_out))) {
+        c->err = "mica_gather_values: bad argument";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    char buf[256] = {0};
+    int r = gather_values_device(d_vol, channels, nvox, d_idx, n, d_out, (hipStream_t)stream, buf, sizeof(buf));
+    if (r) c->err = buf;
+    return r;
+}
+
+int mica_refine_candidates(mica_ctx* c, const float* d_ca, const float* d_aa, int64_t n0, int64_t n1, int64_t n2, const int32_t* d_cand,
+                           int64_t n, double* d_coord, float* d_aa_out, int32_t* d_ok, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_ca || !d_aa || n0 < 1 || n1 < 1 || n2 < 1 || n0 > 4096 || n1 > 4096 || n2 > 4096 || n < 0 ||
+        (n > 0 && (!d_cand || !d_coord || !d_aa_out || !d_ok))) {
+        c->err = "mica_refine_candidates: bad argument";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    char buf[256] = {0};
+    int r = refine_candidates_device(d_ca, d_aa, (int)n0, (int)n1, (int)n2, d_cand, n, d_coord, d_aa_out, d_ok, (hipStream_t)stream, buf,
+                                     sizeof(buf));
+    if (r) c->err = buf;
+    return r;
+}
+
 // ---- single-op entry points (test harness for the individual kernels) ---------------------------
 int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w, const float* h_b,
                    int cout, int k, float* d_y, void* stream) {

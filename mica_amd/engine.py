@@ -191,6 +191,50 @@ class Engine:
                     "mica_rasterise_atoms")
         return out
 
+    # -- point lists for Solver.clustering (modeler.py:762-858) -------------------------------------------------
+    def threshold_points(self, vol: torch.Tensor, thr: float, capacity: int | None = None) -> torch.Tensor:
+        """np.array(np.where(vol > thr)).T as ascending linear indices (int64 device tensor); modeler.py:767."""
+        vol = _f32c(vol, "vol")
+        n = vol.numel()
+        cap = n if capacity is None else int(capacity)
+        while True:
+            idx = torch.empty((max(cap, 1),), dtype=torch.int64, device=self.device)
+            cnt = (C.c_int64 * 1)()
+            self._check(self.lib.mica_threshold_points(self._h, _ptr(vol), n, float(thr), _ptr(idx), cap, cnt, _stream()),
+                        "mica_threshold_points")
+            if cnt[0] <= cap:
+                return idx[:cnt[0]]
+            cap = int(cnt[0])
+
+    def gather_values(self, vol: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """vol f32[N0,N1,N2] or [C,N0,N1,N2], idx int64[n] linear voxel indices -> f32[n] or [C,n]."""
+        vol = _f32c(vol, "vol")
+        c = vol.shape[0] if vol.dim() == 4 else 1
+        nvox = vol.numel() // c
+        if idx.dtype != torch.int64 or not idx.is_cuda:
+            raise MicaHipError("idx: expected an int64 CUDA(HIP) tensor")
+        idx = idx.contiguous()
+        out = torch.empty((c, idx.numel()), dtype=torch.float32, device=self.device)
+        self._check(self.lib.mica_gather_values(self._h, _ptr(vol), c, nvox, _ptr(idx), idx.numel(), _ptr(out), _stream()),
+                    "mica_gather_values")
+        return out if vol.dim() == 4 else out[0]
+
+    def refine_candidates(self, ca: torch.Tensor, aa: torch.Tensor, cands: torch.Tensor):
+        """modeler.py:836-852: cands int32[n,3] -> (coord f64[n,3], aa f32[n,20], ok bool[n])."""
+        ca, aa = _f32c(ca, "ca"), _f32c(aa, "aa")
+        if ca.dim() != 3 or aa.dim() != 4 or aa.shape[0] != 20 or tuple(aa.shape[1:]) != tuple(ca.shape):
+            raise MicaHipError("refine_candidates: ca f32[N0,N1,N2] and aa f32[20,N0,N1,N2] expected")
+        if cands.dtype != torch.int32 or not cands.is_cuda or cands.dim() != 2 or cands.shape[1] != 3:
+            raise MicaHipError("cands: expected an int32 CUDA(HIP) tensor [n,3]")
+        cands = cands.contiguous()
+        n = cands.shape[0]
+        coord = torch.empty((n, 3), dtype=torch.float64, device=self.device)
+        aao = torch.empty((n, 20), dtype=torch.float32, device=self.device)
+        ok = torch.empty((n,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.mica_refine_candidates(self._h, _ptr(ca), _ptr(aa), *ca.shape, _ptr(cands), n, _ptr(coord), _ptr(aao),
+                                                    _ptr(ok), _stream()), "mica_refine_candidates")
+        return coord, aao, ok.bool()
+
     # -- single ops (tests) -----------------------------------------------------------------------------
     def op_conv3d(self, x, w, b, k):
         x = _f32c(x, "x")

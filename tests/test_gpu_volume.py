@@ -348,3 +348,58 @@ def test_af3_rasteriser_edge_cases(eng, tmp_path):
     assert ca[5, 5, 5] == 1 and ca.sum() == 1 and gly[5, 5, 5] == 1 and hd.origin == (1.0, 2.0, 3.0) and hd.nxstart == 4
     assert len(list((tmp_path / "AF3_encodings").glob("*_encoding.mrc"))) == 24
     assert dp.create_AF3_encodings(str(tmp_path / "missing.pdb")) is False
+
+
+def test_cluster_front_end_point_kernels_bit_exact(eng):
+    """The volume-touching steps of Solver.clustering (modeler.py:767, 780-800, 834-858) against the reference's own numpy
+    statements (oracle/cluster_oracle.py; parity unpinned against the module itself: open3d & co. are absent)."""
+    from oracle import cluster_oracle as co
+    rng = np.random.default_rng(77)
+    shape = (37, 50, 41)
+    ca = rng.random(shape, dtype=np.float32) ** 4            # mostly small, a few percent above the threshold
+    ca[0, 0, 0] = ca[-1, -1, -1] = 0.9                       # corner points: kept by the threshold, skipped by the refinement
+    ca[5, 6, 7] = np.nan                                      # NaN > thr is False
+    bb = rng.random(shape, dtype=np.float32)
+    aa = rng.random((20, *shape), dtype=np.float32)
+    aa /= aa.sum(0, keepdims=True)
+    d_ca, d_bb, d_aa = (torch.from_numpy(a).cuda() for a in (ca, bb, aa))
+
+    pts = co.threshold_points(ca, 0.3)                       # int64 [n,3], lexicographic
+    idx = eng.threshold_points(d_ca, 0.3)
+    lin = (pts[:, 0] * shape[1] + pts[:, 1]) * shape[2] + pts[:, 2]
+    assert idx.dtype == torch.int64 and np.array_equal(idx.cpu().numpy(), lin) and 1000 < len(lin) < ca.size // 2
+    assert eng.threshold_points(d_ca, 0.3, capacity=10).numel() == len(lin)      # too small a buffer: retried with the count
+    assert eng.threshold_points(d_ca, 2.0).numel() == 0
+    assert np.array_equal(eng.gather_values(d_bb, idx).cpu().numpy(), co.gather(bb, pts))
+    assert np.array_equal(eng.gather_values(d_aa, idx).cpu().numpy(), aa[:, pts[:, 0], pts[:, 1], pts[:, 2]])
+
+    cands = pts[rng.permutation(len(pts))[:400]]
+    cands = np.concatenate([cands, [[0, 0, 0], [36, 49, 40], [0, 10, 10], [10, 49, 10], [3, 3, 40]]])
+    rc, ra, kept = co.refine_candidates(ca, aa, cands)
+    gc, ga, ok = eng.refine_candidates(d_ca, d_aa, torch.from_numpy(cands.astype(np.int32)).cuda())
+    ok = ok.cpu().numpy()
+    assert np.array_equal(np.nonzero(ok)[0], kept) and (~ok).sum() >= 5
+    assert rc.dtype == np.float64 and ra.dtype == np.float32
+    assert np.array_equal(gc.cpu().numpy()[ok], rc), np.abs(gc.cpu().numpy()[ok] - rc).max()
+    assert np.array_equal(ga.cpu().numpy()[ok], ra)
+    # the host helpers on a volumes dict
+    from mica_amd import clustering as cl
+    vols = {"carbon_alpha_probability": d_ca, "backbone_probability": d_bb, "amino_acid_probability": d_aa}
+    p2, cav, bbv = cl.candidate_points(eng, vols, 0.3)
+    assert np.array_equal(p2, pts) and np.array_equal(cav, co.gather(ca, pts)) and np.array_equal(bbv, co.gather(bb, pts))
+    nc, na, kp = cl.refine(eng, vols, cands)
+    assert np.array_equal(nc, rc) and np.array_equal(na, ra) and np.array_equal(kp, kept)
+    assert np.array_equal(cl.gather_at(eng, d_bb, pts[:50]), co.gather(bb, pts[:50]))
+    # a neighbourhood summing to zero: the reference divides 0/0 and carries the NaNs
+    z = np.zeros(shape, np.float32)
+    gc2, _, ok2 = eng.refine_candidates(torch.from_numpy(z).cuda(), d_aa, torch.tensor([[5, 5, 5]], dtype=torch.int32).cuda())
+    assert bool(ok2[0]) and torch.isnan(gc2).all()
+
+
+def test_threshold_points_full_size_volume(eng):
+    """512^3 (134 M voxels): ascending order, count equal to torch's, every selected voxel above the threshold."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    v = torch.rand((512, 512, 512), generator=g, device="cuda")
+    idx = eng.threshold_points(v, 0.999)
+    assert idx.numel() == int((v > 0.999).sum().item()) and idx.numel() > 100000
+    assert bool((idx[1:] > idx[:-1]).all()) and bool((v.view(-1)[idx] > 0.999).all())
