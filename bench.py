@@ -92,28 +92,45 @@ def main():
     g3 = args.grid
     p = args.pad
     out = torch.zeros((23, n, n, n), dtype=torch.float32, device=dev) if rank == 0 else None
-    gathered = torch.empty((world * B, 23, g3, g3, g3), dtype=torch.float32, device=dev) if world > 1 else None
+    # N > 1: two slots, so that the all-gather of step k (async, on RCCL's stream) overlaps the compute of step k+1
+    gathered = [torch.empty((world * B, 23, g3, g3, g3), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    crops = [torch.empty((B, 23, g3, g3, g3), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    pending = []
+
+    def finish():
+        work, k, slot = pending.pop()
+        work.wait()
+        if rank == 0:
+            # cropped records carry no halo: stitch them with pad 0 on a grid-sized window
+            for r in range(world):
+                f = ((k * world + r) * B) % max(T - B + 1, 1)
+                eng.stitch_tiles(gathered[slot][r * B:(r + 1) * B], out, g3, 0, f)
 
     def step(k):
         first = ((k * world + rank) * B) % max(T - B + 1, 1)
         rec = vp.run_batch(vol, af, first, B)
         if world == 1:
             eng.stitch_tiles(rec, out, args.grid, p, first)
-        else:
-            crop = rec[:, :, p:p + g3, p:p + g3, p:p + g3].contiguous()
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, crop)
-            else:                                   # gloo rehearsal: stage through the host
-                parts = [torch.empty(crop.shape, dtype=crop.dtype) for _ in range(world)]
-                dist.all_gather(parts, crop.cpu())
-                gathered.copy_(torch.cat(parts).to(dev))
-            if rank == 0:
-                # cropped records carry no halo: stitch them with pad 0 on a grid-sized window
-                for r in range(world):
-                    f = ((k * world + r) * B) % max(T - B + 1, 1)
-                    eng.stitch_tiles(gathered[r * B:(r + 1) * B], out, g3, 0, f)
+            return
+        slot = k & 1
+        crops[slot].copy_(rec[:, :, p:p + g3, p:p + g3, p:p + g3])
+        if args.backend == "nccl":
+            work = dist.all_gather_into_tensor(gathered[slot], crops[slot], async_op=True)
+        else:                                   # gloo rehearsal: stage through the host
+            class _Done:
+                def wait(self):
+                    pass
+            parts = [torch.empty(crops[slot].shape, dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(parts, crops[slot].cpu())
+            gathered[slot].copy_(torch.cat(parts).to(dev))
+            work = _Done()
+        if pending:
+            finish()                            # step k-1: its gather ran beside this step's kernels
+        pending.append((work, k, slot))
 
     def sync():
+        if pending:
+            finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
