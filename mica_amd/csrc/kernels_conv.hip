@@ -1,9 +1,11 @@
-// Dense convolution on gfx950 matrix cores: implicit GEMM over 16-channel chunks with split-f16
-// operands (x = hi + lo, three v_mfma_f32_32x32x16_f16 per product: lo*hi, hi*lo, hi*hi), which keeps
-// ~22 mantissa bits per product at 3/16 of the f32-MFMA cost (MI355X: f32 MFMA 157 TF, f16 2.5 PF).
-// Replaces nn.Conv3d(k=3,pad=1) / nn.Conv3d(k=1) of reference models/model.py:17,28,38,96,107,115,122,
-// 142,158-174,210,212.  Also: weight packing, depthwise 3^3 (model.py:80) and the Cin=1 multi-scale
-// stem (model.py:9-14).
+// Dense convolution on gfx950 matrix cores: implicit GEMM over 16-channel chunks with split-f16 operands (x = hi + lo,
+// three f16 MFMA products per f32-grade product: lo*hi, hi*lo, hi*hi), which keeps ~22 mantissa bits per product at 3/16
+// of the f32-MFMA cost (MI355X: f32 MFMA 157 TF, f16 2.5 PF).  Replaces nn.Conv3d(k=3,pad=1) / nn.Conv3d(k=1) of reference
+// models/model.py:17,28,38,96,107,115,122,142,158-174,210,212.
+//   conv_wino16_kernel<128|64|32> : every 3^3 conv - Winograd F(2,3) along x, v_mfma_f32_16x16x32_f16, persistent
+//   conv2_kernel<1,...>           : the 1x1x1 convs (direct; also the 3^3 fallback under MICA_WINO=0)
+//   conv_wino_kernel<BN,WN>       : the first Winograd kernel (v_mfma_f32_32x32x16_f16), MICA_W16=0 fallback
+// Also here: weight packing, the depthwise 3^3 conv (model.py:80) and the Cin=1 multi-scale stem (model.py:9-14).
 #include "common.h"
 #include <vector>
 #include <algorithm>
