@@ -1,17 +1,23 @@
 """Headline benchmark: 64^3 sub-grids/s of the MICA hot path (tile gather -> network forward ->
-softmax/argmax -> stitch) on synthetic maps resident in HBM.  One JSON line on rank 0.
+softmax/argmax -> stitch) on a synthetic 512^3 map resident in HBM (BASELINE.json's metric config).
+One JSON line on rank 0.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py [--gpus 1] --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...          (no launcher: this process touches no GPU and starts the N ranks itself)
+  python bench.py --gpus 2 --backend gloo --single-device      (rehearse the N>1 path on one GPU)
 
-A step = one batch of `--batch` tiles through the whole path.  N=1: BASELINE.json configs[1]
-(synthetic 256^3 map, stride-32 tiling = grid 32 + 2*16 halo -> 512 tiles of 64^3); N>1: configs[2]
-(synthetic 512^3 map, 4096 tiles) with tile batches dealt round-robin to the ranks and the cropped
-per-tile records all-gathered over RCCL/xGMI so that rank 0 stitches the volumes.
+A step = one batch of `--batch` tiles per GPU through the whole path.  The map is the synthetic 512^3 map at
+every N (it fits one GPU: 0.54 GB map + 12.9 GB encodings + 12.3 GB output volumes + ~40 GB workspace);
+"stride-32" tiling = grid 32 + 2*16 halo -> 4096 windows of 64^3.  N>1: tile batches are dealt round-robin to the
+ranks (mica_amd/dist.py: the code `predict_volume_sharded` ships) and the cropped per-tile records are all-gathered over
+RCCL/xGMI so that rank 0 stitches the volumes.  At N=1 the rate at the reference's default tiling (48, 8) -> 1331
+windows of the same 64^3 size is measured too (`alt_tiling`).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,40 +27,109 @@ sys.path.insert(0, ROOT)
 FLOPS_PER_TILE_AF = 7.3625e12       # BASELINE.md section 3 (AF path), measured on the reference model
 PEAK_F16_MFMA_TF = 2500.0           # MI355X dense f16 MFMA (MI355X_MICROARCH.md)
 PEAK_SPLIT_TF = PEAK_F16_MFMA_TF / 3.0   # this path spends three f16 MFMAs per f32-grade product
+WINO_MFMA_PER_ALGORITHMIC = 3.0 * (14.0 / 13.5) / 1.5      # executed f16 MFMA flops per algorithmic flop of a 3^3 conv
 
 
-def cpu_baseline(weights, tile_map, tile_af, threads):
-    """The CPU oracle (validated bit-exact against the reference module) timed on this host:
-    one 64^3 tile of the same workload, AF path, batch 1."""
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 8
+    return max(1, min(n, 16))       # a one-GPU box's CPU share is 16
+
+
+def cpu_baseline(weights, tiles_map, tiles_af, vol_host):
+    """The CPU oracle (torch CPU fp32 = the reference CPU path's arithmetic; validated bit-exact against the reference
+    module in the build container) timed on this host per BASELINE.md section 4: one warm-up tile, then timed tiles of
+    the same synthetic map, AF path, batch 1, at all usable cores and at 8 threads; plus the numpy tiler / stitch /
+    normaliser on the same map."""
+    import numpy as np
     import torch
     from oracle import model_oracle as mo   # cpu_baseline leg only
-    torch.set_num_threads(threads)
-    t0 = time.time()
-    mo.mica_forward(weights, tile_map, tile_af)
-    dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "sub-grids/s", "cores": threads, "kind": "port",
-            "sample": "1 tile of 64^3 (AF path, batch 1, torch CPU fp32) of the same synthetic map, %.1f s" % dt}
+    from oracle import volume_oracle as vo
+
+    def run(threads, idxs):
+        torch.set_num_threads(threads)
+        ts = []
+        for i in idxs:
+            t0 = time.perf_counter()
+            mo.mica_forward(weights, tiles_map[i:i + 1], tiles_af[i:i + 1])
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    k = host_threads()
+    run(k, [0])                                          # warm-up (untimed)
+    full = run(k, [1, 2, 3])
+    out = {"value": len(full) / sum(full), "unit": "sub-grids/s", "cores": k, "kind": "port",
+           "sample": "3 timed 64^3 tiles (after 1 warm-up) of the same synthetic map, AF path, batch 1, torch CPU fp32, "
+                     "%.1f s; a whole 4096-tile map is extrapolated linearly (tiles are independent and equal cost)" % sum(full),
+           "seconds_per_tile": full}
+    if k != 8:
+        run(8, [0])
+        t8 = run(8, [1, 2])
+        out["threads_8"] = {"value": len(t8) / sum(t8), "cores": 8, "seconds_per_tile": t8}
+    # the reference's numpy stages on the same map (single thread, as in the reference)
+    n = vol_host.shape[0]
+    m = min(n, 256)                                      # the spline resample costs ~8 s per 256^3 on one core: bounded sample
+    t0 = time.perf_counter()
+    vo.normalise_map(np.ascontiguousarray(vol_host[:m, :m, :m]) - np.float32(0.3))
+    t_norm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tiles, idx = vo.tile_volume(vol_host, 48, 8)
+    t_tile = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    vo.stitch_volume(tiles, idx, vol_host.shape, 8)
+    t_stitch = time.perf_counter() - t0
+    out["stages"] = {"map": f"{n}^3", "normalise_s": t_norm, "normalise_sample": f"{m}^3 corner of the map (scale by {(n / m) ** 3:.0f} for the whole map)", "tile_one_channel_s": t_tile, "stitch_one_channel_s": t_stitch,
+                     "tiles": int(len(idx)),
+                     "note": "numpy restatements of preprocessing.py:117-133 (zoom factor 1), create_grids.py:129-157 and "
+                             "predict.py:459-501 on one channel, default tiling (48, 8); the reference tiles 25 channels and stitches 23"}
+    return out
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this one has not touched the GPU),
+    relay their output; rank 0 prints the JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--map", type=int, default=0, help="map edge (default 256 at N=1, 512 at N>1)")
+    ap.add_argument("--map", type=int, default=512, help="map edge (BASELINE metric: 512)")
     ap.add_argument("--grid", type=int, default=32)
     ap.add_argument("--pad", type=int, default=16)
     ap.add_argument("--no-af", action="store_true", help="zero-AF path (exp_downsizing branch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-tiling", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args, sys.argv[1:])
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
+    from mica_amd.dist import RecordExchange
     from mica_amd.engine import Engine
     from mica_amd.pipeline import VolumePredictor
     from mica_amd.weights import synth_state_dict
@@ -63,7 +138,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.single_device:
         local = 0
     torch.cuda.set_device(local)
@@ -74,63 +149,47 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    n = args.map or (256 if world == 1 else 512)
+    n = args.map
     B = args.batch
     dev = torch.device("cuda", local)
-    rng = np.random.default_rng(1001 if n == 256 else 1002)
-    vol = torch.from_numpy(rng.random((n, n, n), dtype=np.float32)).to(dev)
+    seed = {256: 1001, 512: 1002}.get(n, 1000 + n)
+    vol_host = np.random.default_rng(seed).random((n, n, n), dtype=np.float32)
+    vol = torch.from_numpy(vol_host).to(dev)
     af = None
     if not args.no_af:
-        # 24 binary channels with ~1e-3 occupancy, generated on the device
+        # 24 binary channels with ~1e-3 occupancy, generated on the device channel by channel
         g = torch.Generator(device=dev).manual_seed(2001)
-        af = (torch.rand((24, n, n, n), generator=g, device=dev) < 1e-3).float()
+        af = torch.empty((24, n, n, n), dtype=torch.float32, device=dev)
+        for c in range(24):
+            af[c] = (torch.rand((n, n, n), generator=g, device=dev) < 1e-3).float()
     weights = synth_state_dict(2022)
-    eng = Engine(local, max_batch=B, tile_size=args.grid + 2 * args.pad)
+    S = args.grid + 2 * args.pad
+    eng = Engine(local, max_batch=B, tile_size=S)
     eng.load_state_dict(weights)
     vp = VolumePredictor(eng, args.grid, args.pad, B)
     T = int(eng.lib.mica_tile_count(n, n, n, args.grid))
-    g3 = args.grid
-    p = args.pad
+    g3, p = args.grid, args.pad
     out = torch.zeros((23, n, n, n), dtype=torch.float32, device=dev) if rank == 0 else None
-    # N > 1: two slots, so that the all-gather of step k (async, on RCCL's stream) overlaps the compute of step k+1
-    gathered = [torch.empty((world * B, 23, g3, g3, g3), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
-    crops = [torch.empty((B, 23, g3, g3, g3), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
-    pending = []
+    nb = max(T // B, 1)                         # whole batches per map; step k wraps around the map
 
-    def finish():
-        work, k, slot = pending.pop()
-        work.wait()
-        if rank == 0:
-            # cropped records carry no halo: stitch them with pad 0 on a grid-sized window
-            for r in range(world):
-                f = ((k * world + r) * B) % max(T - B + 1, 1)
-                eng.stitch_tiles(gathered[slot][r * B:(r + 1) * B], out, g3, 0, f)
+    def first_of(k, r):
+        return ((k * world + r) % nb) * B
 
-    def step(k):
-        first = ((k * world + rank) * B) % max(T - B + 1, 1)
-        rec = vp.run_batch(vol, af, first, B)
+    ex = None
+    if world > 1:
+        # cropped records carry no halo: stitched with pad 0 on a grid-sized window
+        ex = RecordExchange(B, (23, g3, g3, g3), dev, lambda rec, first: eng.stitch_tiles(rec, out, g3, 0, first), stitch_rank=0)
+
+    def step(k, pred=vp, grid=g3, pad=p):
+        rec = pred.run_batch(vol, af, first_of(k, rank), B)
         if world == 1:
-            eng.stitch_tiles(rec, out, args.grid, p, first)
-            return
-        slot = k & 1
-        crops[slot].copy_(rec[:, :, p:p + g3, p:p + g3, p:p + g3])
-        if args.backend == "nccl":
-            work = dist.all_gather_into_tensor(gathered[slot], crops[slot], async_op=True)
-        else:                                   # gloo rehearsal: stage through the host
-            class _Done:
-                def wait(self):
-                    pass
-            parts = [torch.empty(crops[slot].shape, dtype=torch.float32) for _ in range(world)]
-            dist.all_gather(parts, crops[slot].cpu())
-            gathered[slot].copy_(torch.cat(parts).to(dev))
-            work = _Done()
-        if pending:
-            finish()                            # step k-1: its gather ran beside this step's kernels
-        pending.append((work, k, slot))
+            eng.stitch_tiles(rec, out, grid, pad, first_of(k, 0))
+        else:
+            ex.post(k, rec[:, :, p:p + g3, p:p + g3, p:p + g3], [(first_of(k, r), B) for r in range(world)])
 
     def sync():
-        if pending:
-            finish()
+        if ex is not None:
+            ex.flush()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -151,6 +210,27 @@ def main():
     tiles = args.steps * B * world
     value = tiles / dt
 
+    # the same map at the reference's default tiling (48, 8): 1331 windows of the same 64^3 size
+    alt = None
+    if rank == 0 and world == 1 and not args.no_alt_tiling and S == 64:
+        vp48 = VolumePredictor(eng, 48, 8, B)
+        T48 = int(eng.lib.mica_tile_count(n, n, n, 48))
+        ks = max(args.steps // 2, 4)
+        out.zero_()
+
+        def step48(k):
+            f = (k % max(T48 // B, 1)) * B
+            eng.stitch_tiles(vp48.run_batch(vol, af, f, B), out, 48, 8, f)
+        step48(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(ks):
+            step48(1 + k)
+        torch.cuda.synchronize()
+        d48 = time.perf_counter() - t1
+        alt = {"tiling": "grid 48 + 2x8 halo (reference default)", "tiles_per_map": T48, "value": ks * B / d48,
+               "unit": "sub-grids/s", "steps": ks, "seconds_per_map": T48 / (ks * B / d48)}
+
     # rooflines: HIP events (on the launch stream, inside the library) around every dense-conv and every depthwise
     # conv3d launch of one extra, untimed batch.  PMC traffic comes from the committed rocprofv3 passes (profiles/).
     roof = hbm = None
@@ -160,20 +240,28 @@ def main():
         torch.cuda.synchronize()
         ms, launches, flops = eng.profile(0)
         dms, dl, dbytes = eng.profile(1)
+        wms, wl, wflops = eng.profile(2)
         eng.set_profiling(False)
         traffic = {}
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")     # re-collected whenever the conv kernels change
-        if os.path.exists(tp) and B == 8 and n == 256 and not args.no_af:      # measured for exactly this workload
+        tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # re-collected whenever the conv kernels change
+        if os.path.exists(tp) and B == 8 and not args.no_af:            # per launch at batch 8; independent of the map size
             traffic = json.load(open(tp)).get("kernels", {})
         ach = flops / (ms * 1e-3) / 1e12
+        wach = wflops / (wms * 1e-3) / 1e12 if wms > 0 else 0.0
         roof = {"bound": "mfma", "kernel": "conv_wino16_kernel (+ conv2_kernel for 1x1x1): dense 3x3x3 via Winograd F(2,3)-x, split-f16 x3 MFMA",
                 "achieved": ach, "peak": PEAK_SPLIT_TF, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TF,
-                "traffic": traffic.get("conv_wino16_kernel", traffic.get("conv_wino_kernel", {})).get("hbm_bytes"),
+                "traffic": traffic.get("conv_wino16_kernel", {}).get("hbm_bytes"),
                 "launches_per_batch": launches, "avg_launch_ms": ms / max(launches, 1),
                 "algorithmic_gflop_per_launch_avg": flops / max(launches, 1) / 1e9,
+                "executed_mfma": {"achieved": wach * WINO_MFMA_PER_ALGORITHMIC, "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s (f16 MFMA issued)",
+                                  "frac": wach * WINO_MFMA_PER_ALGORITHMIC / PEAK_F16_MFMA_TF,
+                                  "note": "3x3x3 layers only: algorithmic FLOPs / 1.5 (Winograd) x 3 (split products) x 14/13.5 (tap pairing) "
+                                          "= f16 MFMA FLOPs the kernel issues, over the 2.5 PF dense f16 peak"},
                 "note": "achieved = algorithmic direct-conv FLOPs (2*k^3*Cin*Cout*V, unpadded) / HIP-event time of the conv launches; "
-                        "peak = f16 dense MFMA 2500 TF / 3 MFMAs per f32-grade product; Winograd executes 1.5x fewer MFMAs than the "
-                        "algorithmic count; traffic = PMC HBM bytes per conv_wino16 launch of `python bench.py` defaults (batch 8; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections, profiles/r01_pmc_traffic.json); null for other batch sizes"}
+                        "peak = f16 dense MFMA 2500 TF / 3 MFMAs per f32-grade product (833 TF); with Winograd the kernel executes 1.5x fewer "
+                        "MFMAs than the algorithmic count, so this fraction is an algorithmic rate, `executed_mfma` is the hardware fraction; "
+                        "traffic = PMC HBM bytes per conv_wino16 launch at batch 8 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                        "gfx950 corrections, profiles/r02_pmc_traffic.json); null for other batch sizes"}
         dach = dbytes / (dms * 1e-3) / 1e9
         hbm = {"bound": "hbm", "kernel": "depthwise_kernel (Conv3d groups=C, 3x3x3, IN+ReLU+SE gate fused on load, IN stats fused)",
                "achieved": dach, "peak": 8000.0, "unit": "GB/s", "frac": dach / 8000.0,
@@ -182,10 +270,11 @@ def main():
                "note": "BASELINE metric's 'HBM GB/s on conv3d': algorithmic 8 B per voxel and channel / HIP-event time"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
-        S = args.grid + 2 * args.pad
-        tm = eng.gather_tiles(vol, args.grid, p, T // 2, 1).cpu()
-        ta = eng.gather_tiles(af, args.grid, p, T // 2, 1).cpu() if af is not None else None
-        cpu = cpu_baseline(weights, tm.view(1, 1, S, S, S), ta, threads=min(os.cpu_count() or 8, 16))
+        first = (T // 2 // 4) * 4
+        tm = eng.gather_tiles(vol, g3, p, first, 4).cpu().view(4, 1, S, S, S)
+        ta = eng.gather_tiles(af, g3, p, first, 4).cpu() if af is not None else torch.zeros((4, 24, S, S, S))
+        del out
+        cpu = cpu_baseline(weights, tm, ta, vol_host)
     if rank == 0:
         print(json.dumps({
             "metric": "64^3 sub-grids/sec", "value": value, "unit": "sub-grids/s", "n_gpus": world, "steps": args.steps,
@@ -194,8 +283,9 @@ def main():
             "config": {"workload": f"synthetic {n}^3 density map + 24-ch AF3 encodings, window 64 = grid {args.grid} + 2x{args.pad} halo, "
                                    f"{T} tiles per map, {B} tiles per step per GPU, gather+forward+softmax+stitch"
                                    + ("" if world == 1 else ", RCCL all-gather of cropped records to every rank, rank 0 stitches"),
-                       "tiles_per_step": B * world, "af_path": not args.no_af, "flops_per_tile": FLOPS_PER_TILE_AF},
-            "roofline": roof, "hbm_conv3d": hbm, "cpu_baseline": cpu}))
+                       "tiles_per_step": B * world, "af_path": not args.no_af, "flops_per_tile": FLOPS_PER_TILE_AF,
+                       "seconds_per_map": T / value},
+            "alt_tiling": alt, "roofline": roof, "hbm_conv3d": hbm, "cpu_baseline": cpu}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

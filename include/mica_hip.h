@@ -151,8 +151,9 @@ int mica_op_stem(mica_ctx* ctx, const float* d_map, int batch, int d, int h, int
  * profiling was enabled with mica_set_profiling(ctx, 1): sum and launch count.               */
 int mica_set_profiling(mica_ctx* ctx, int enable);
 int mica_get_conv_profile(mica_ctx* ctx, double* h_ms_total, int64_t* h_launches, double* h_flops);
-/* kind 0 = dense conv launches (work = algorithmic FLOPs), kind 1 = depthwise conv3d launches (work = algorithmic
- * HBM bytes, 8 B per voxel and channel).                                                          */
+/* kind 0 = dense conv launches (work = algorithmic FLOPs; = kinds 2 + 4), kind 1 = depthwise conv3d launches (work =
+ * algorithmic HBM bytes, 8 B per voxel and channel), kind 2 = 3x3x3 convs only, kind 3 = operand passes (InstanceNorm
+ * apply + ReLU + re-encode; work = algorithmic bytes), kind 4 = 1x1x1 convs only.                  */
 int mica_get_profile(mica_ctx* ctx, int kind, double* h_ms_total, int64_t* h_launches, double* h_work);
 
 #ifdef __cplusplus

@@ -105,7 +105,6 @@ void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_se
 int64_t packed_weight_halves_wino(int cout, int total_chunks);
 void launch_postprocess(const float* bb, const float* ca, const float* aa, int B, int V, float* bbp, float* cap,
                         float* aap, float* aapred, hipStream_t st);
-void launch_fill_half(_Float16* p, int64_t n, hipStream_t st);
 
 void launch_gather_tiles(const float* vol, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
                          int64_t first, int64_t count, float* tiles, hipStream_t st);

@@ -30,7 +30,7 @@ struct ConvLayer {
     float cout_scale = 1.f;           // folded output scale (FPN softmax weight, model.py:201-205)
     float wscale = 1.f;               // power of two bringing max|w| to ~4096 (f16 hi/lo stay normal)
     bool per_tile = false;            // weights re-packed per tile with a gate folded in (cin_scale)
-    bool wino = false;                // 3^3 conv on the Winograd F(2,3)-along-x path
+    bool wino = false;                // 3^3 conv: Winograd F(2,3)-along-x kernel and operand layout
     float* d_w = nullptr;             // torch layout f32
     float* d_b = nullptr;             // bias (already times cout_scale)
     _Float16* d_wpk = nullptr;        // packed (static) or per-tile buffer [maxB][...]
@@ -60,6 +60,8 @@ struct Head {
 
 }  // namespace
 
+constexpr int PROF_KINDS = 5;
+
 struct mica_ctx {
     int device = 0, maxB = 1, S = 64;
     Dims d{64, 64, 64};
@@ -80,10 +82,9 @@ struct mica_ctx {
     Head heads[3];
 
     // activations
-    // operands of 3^3 convs are in wino layout (2x bytes) when `wino`, else plain split; S_cp = plain copies for the 1x1 laterals
+    // operands of 3^3 convs are in wino layout (2x bytes), those of 1x1 convs plain split; S_cp = plain copies for the 1x1 laterals
     _Float16 *S_exp, *S_af, *S_fw, *S_x0, *S_1, *S_2, *S_3, *S_dw, *S_f, *S_c[3], *S_cp[3], *S_l, *S_fpn, *S_extra, *S_h1;
     float* extra_raw = nullptr;   // [B][8][V] backbone + CA logits (NCDHW) feeding the next heads' conv1
-    bool wino = true;
     float *R_a, *R_b, *R_c;
     float *logits[3];             // internal NCDHW logits when the caller wants probabilities only
     float* ws = nullptr;          // reduction partials
@@ -92,14 +93,15 @@ struct mica_ctx {
     float* h_abs = nullptr;       // pinned
     int* h_err = nullptr;         // pinned
 
-    // profiling: HIP events around the launches of kind 0 = dense conv (work = FLOPs), 1 = depthwise conv3d (work = bytes)
+    // profiling: HIP events around the launches of kind 0 = every dense conv (= kinds 2 + 4, work = FLOPs), 1 = depthwise
+    // conv3d (work = bytes), 2 = 3^3 convs (Winograd kernel), 3 = operand passes (prep kernels, work = bytes), 4 = 1x1 convs
     bool profiling = false;
     std::vector<hipEvent_t> ev;
     std::vector<int> ev_kind;
     size_t ev_used = 0;
-    double prof_work[2] = {0, 0};
-    double last_ms[2] = {0, 0}, last_work[2] = {0, 0};
-    int64_t last_launches[2] = {0, 0};
+    double prof_work[PROF_KINDS] = {};
+    double last_ms[PROF_KINDS] = {}, last_work[PROF_KINDS] = {};
+    int64_t last_launches[PROF_KINDS] = {};
 };
 
 namespace {
@@ -185,7 +187,7 @@ int setup_conv(mica_ctx* c, ConvLayer& L, const std::string& name, int cout, int
     for (float& v : bs) v *= cout_scale;
     r = upload(c, &L.d_b, bs);
     if (r) return r;
-    L.wino = (k == 3) && c->wino;
+    L.wino = (k == 3);
     L.pk_halves = L.wino ? packed_weight_halves_wino(cout, L.total_chunks) : packed_weight_halves(cout, k, L.total_chunks);
     r = dalloc(c, &L.d_wpk, L.pk_halves * (per_tile ? c->maxB : 1));
     if (r) return r;
@@ -253,7 +255,8 @@ void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, 
     if (L.per_tile)
         launch_pack_weights(L.d_w, L.cout, L.cin, L.k, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(),
                             L.d_cin_scale, B, L.cout_scale, L.wscale, L.d_wpk, st);
-    prof_begin(c, 0, st);
+    const int pk = L.k == 3 ? 2 : 4;
+    prof_begin(c, pk, st);
     int P = 0;
     if (L.wino)
         P = launch_conv_wino(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
@@ -261,7 +264,7 @@ void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, 
     else
         launch_conv_mfma(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
                          L.k, c->d_err, st);
-    prof_end(c, 0, L.flops_per_voxel * (double)c->V * B, st);
+    prof_end(c, pk, L.flops_per_voxel * (double)c->V * B, st);
     if (mean) {
         if (L.wino) launch_stats_finalize(c->ws, B, P, L.cout, 1e-5f, mean, rstd, st);
         else launch_stats(out, B, c->V, L.cout, 1e-5f, mean, rstd, c->ws, st);
@@ -277,13 +280,14 @@ void gate(mica_ctx* c, const GateMLP& g, const float* pool, const float* premul,
 // Winograd path is on, else plain split), `t1` feeds 1x1 convs (always plain split).  Either may be empty.
 void make_operand(mica_ctx* c, const float* raw, int B, int C, const float* mean, const float* rstd, int relu, SplitView t3,
                   SplitView t1, float* gap, hipStream_t st) {
-    if (c->wino && t3.p) {
+    prof_begin(c, 3, st);
+    // algorithmic bytes: the f32 tensor read once, each operand written once (wino layout = 8 B, plain split = 4 B per value)
+    const double bytes = (double)B * c->V * C * (4.0 + (t3.p ? 8.0 : 0.0) + (t1.p ? 4.0 : 0.0));
+    struct End { mica_ctx* c; double b; hipStream_t s; ~End() { prof_end(c, 3, b, s); } } end_{c, bytes, st};
+    if (t3.p) {
         launch_prep_wino(raw, B, c->d, C, mean, rstd, relu, nullptr, t3, t1, gap, c->ws, c->d_err, st);
     } else {
-        SplitView o = t3.p ? t3 : t1;
-        launch_prep(raw, B, c->V, C, mean, rstd, relu, nullptr, o, nullptr, gap, c->ws, c->d_err, st);
-        if (t3.p && t1.p && t1.p != t3.p)
-            launch_prep(raw, B, c->V, C, mean, rstd, relu, nullptr, t1, nullptr, nullptr, c->ws, c->d_err, st);
+        launch_prep(raw, B, c->V, C, mean, rstd, relu, nullptr, t1, nullptr, gap, c->ws, c->d_err, st);
     }
 }
 
@@ -300,8 +304,7 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         run_conv(c, c->downsizing, SrcList().add(c->S_exp, 8, 0, 8), c->R_a, B, st);
     } else {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->fusion0.d_cin_scale, 192, st);
-        if (c->wino) launch_prep_ncdhw_wino(d_af, B, d, 24, view(c->S_af, 2, 0, 2), c->d_err, st);
-        else launch_prep_ncdhw(d_af, B, V, 24, view(c->S_af, 2, 0, 2), nullptr, c->d_err, st);
+        launch_prep_ncdhw_wino(d_af, B, d, 24, view(c->S_af, 2, 0, 2), c->d_err, st);
         run_conv(c, c->feat_conv, SrcList().add(c->S_af, 2, 0, 2), c->R_b, B, st);
         launch_feat_gate(c->R_b, B, V, c->fg_w0, c->fg_b0, c->fg_w2, c->fg_b2, view(c->S_fw, 4, 0, 4), c->d_err, st);
         run_conv(c, c->fusion0, SrcList().add(c->S_exp, 8, 0, 8).add(c->S_fw, 4, 0, 4), c->R_a, B, st);
@@ -350,8 +353,7 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         make_operand(c, c->R_b, B, 64, nullptr, nullptr, 0, view(c->S_fpn, 12, 4 * i, 4), none, nullptr, st);
     }
     // ---- heads (model.py:230-239, 344-346) ------------------------------------------------------
-    if (c->wino) hipMemsetAsync(c->extra_raw, 0, sizeof(float) * (size_t)B * 8 * V, st);
-    else launch_fill_half(c->S_extra, (int64_t)B * V * 32, st);
+    hipMemsetAsync(c->extra_raw, 0, sizeof(float) * (size_t)B * 8 * V, st);
     float* outs[3] = {o_bb, o_ca, o_aa};
     for (int h = 0; h < 3; ++h) {
         Head& H = c->heads[h];
@@ -364,10 +366,9 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         launch_prep(c->R_b, B, V, 32, c->v_mean, c->v_rstd, 1, nullptr, none, nullptr, c->v_pool, c->ws, c->d_err, st);
         gate(c, H.cal, c->v_pool, nullptr, B, nullptr, c->v_gate, nullptr, 0, st);
         const bool feeds = h < 2;
-        launch_head_final(c->R_b, B, V, c->v_mean, c->v_rstd, c->v_gate, H.wf, H.bf, H.ncls, outs[h],
-                          (feeds && !c->wino) ? view(c->S_extra, 1, 0, 1) : none, 4 * h, (feeds && c->wino) ? c->extra_raw : nullptr,
-                          8, st);
-        if (feeds && c->wino) launch_prep_ncdhw_wino(c->extra_raw, B, d, 8, view(c->S_extra, 1, 0, 1), c->d_err, st);
+        launch_head_final(c->R_b, B, V, c->v_mean, c->v_rstd, c->v_gate, H.wf, H.bf, H.ncls, outs[h], none, 4 * h,
+                          feeds ? c->extra_raw : nullptr, 8, st);
+        if (feeds) launch_prep_ncdhw_wino(c->extra_raw, B, d, 8, view(c->S_extra, 1, 0, 1), c->d_err, st);
     }
     return MICA_OK;
 }
@@ -381,7 +382,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     HIPC(c, hipSetDevice(c->device));
     const int V = c->V;
     c->ev_used = 0;
-    c->prof_work[0] = c->prof_work[1] = 0;
+    for (double& w : c->prof_work) w = 0;
     HIPC(c, hipMemsetAsync(c->d_err, 0, sizeof(int), st));
     std::vector<char> use(B, 0);
     if (d_af && af_mode != MICA_AF_NONE) {
@@ -409,15 +410,16 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     HIPC(c, hipGetLastError());
     if (c->profiling) {
         HIPC(c, hipStreamSynchronize(st));
-        double ms[2] = {0, 0};
-        int64_t n[2] = {0, 0};
+        double ms[PROF_KINDS] = {};
+        int64_t n[PROF_KINDS] = {};
         for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
             float t = 0;
             hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]);
             ms[c->ev_kind[i]] += t;
             n[c->ev_kind[i]]++;
         }
-        for (int k = 0; k < 2; ++k) { c->last_ms[k] = ms[k]; c->last_launches[k] = n[k]; c->last_work[k] = c->prof_work[k]; }
+        ms[0] = ms[2] + ms[4]; n[0] = n[2] + n[4]; c->prof_work[0] = c->prof_work[2] + c->prof_work[4];
+        for (int k = 0; k < PROF_KINDS; ++k) { c->last_ms[k] = ms[k]; c->last_launches[k] = n[k]; c->last_work[k] = c->prof_work[k]; }
     }
     return MICA_OK;
 }
@@ -485,20 +487,14 @@ int mica_create(int device, int max_batch, int tile_size, mica_ctx** out) {
     c->V = tile_size * tile_size * tile_size;
     const int64_t BV = (int64_t)max_batch * c->V;
     int r = 0;
-    {
-        const char* e = getenv("MICA_WINO");
-        c->wino = !(e && e[0] == '0');
-    }
     // wino layout holds 4 transformed values per output pair: 2x the plain bytes (pairs = ceil(W/2) per row)
     const int64_t BVw = (int64_t)max_batch * tile_size * tile_size * ((tile_size + 1) / 2) * 4;
     auto S = [&](_Float16** p, int ch) { if (!r) r = dalloc(c, p, BV * ch * 2); };                        // plain: hi + lo
-    auto W3 = [&](_Float16** p, int ch) { if (!r) r = dalloc(c, p, (c->wino ? BVw : BV) * ch * 2); };      // operand of 3^3 convs
+    auto W3 = [&](_Float16** p, int ch) { if (!r) r = dalloc(c, p, BVw * ch * 2); };                       // operand of 3^3 convs
     S(&c->S_exp, 128); W3(&c->S_af, 32); S(&c->S_fw, 64); W3(&c->S_x0, 64);
     W3(&c->S_1, 128); W3(&c->S_2, 128); S(&c->S_3, 256); S(&c->S_dw, 256); W3(&c->S_f, 256);
     W3(&c->S_c[0], 128); W3(&c->S_c[1], 256); c->S_c[2] = nullptr;
-    if (c->wino) { S(&c->S_cp[0], 128); S(&c->S_cp[1], 256); }
-    S(&c->S_cp[2], 512);
-    if (!c->wino) { c->S_cp[0] = c->S_c[0]; c->S_cp[1] = c->S_c[1]; }
+    S(&c->S_cp[0], 128); S(&c->S_cp[1], 256); S(&c->S_cp[2], 512);
     W3(&c->S_l, 64); W3(&c->S_fpn, 192); W3(&c->S_extra, 16); W3(&c->S_h1, 64);
     if (!r) r = dalloc(c, &c->extra_raw, BV * 8);
     auto R = [&](float** p, int ch) { if (!r) r = dalloc(c, p, BV * ch); };
@@ -826,7 +822,7 @@ int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int
     HIPC(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const int V = d * h * w, cp = pad16(cin), nt = k * k * k;
-    const bool wino = (k == 3) && c->wino;
+    const bool wino = (k == 3);
     const int64_t Vop = wino ? (int64_t)d * h * ((w + 1) / 2) * 4 : V;
     Tmp t;
     _Float16* sx = t.get<_Float16>((int64_t)batch * Vop * cp * 2);
@@ -935,7 +931,7 @@ int mica_set_profiling(mica_ctx* c, int enable) {
 }
 
 int mica_get_profile(mica_ctx* c, int kind, double* h_ms_total, int64_t* h_launches, double* h_work) {
-    if (!c || kind < 0 || kind > 1 || !h_ms_total || !h_launches || !h_work) return MICA_ERR_ARG;
+    if (!c || kind < 0 || kind >= PROF_KINDS || !h_ms_total || !h_launches || !h_work) return MICA_ERR_ARG;
     *h_ms_total = c->last_ms[kind];
     *h_launches = c->last_launches[kind];
     *h_work = c->last_work[kind];

@@ -673,13 +673,6 @@ __global__ void fill_float_kernel(float* p, int64_t n, float v) {
 void launch_fill_float(float* p, int64_t n, float v, hipStream_t st) {
     hipLaunchKernelGGL(fill_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
 }
-__global__ void fill_half_kernel(_Float16* p, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = (_Float16)0.f;
-}
-void launch_fill_half(_Float16* p, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(fill_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Tile gather (create_grids.py:129-157): window W = grid + 2*pad at stride grid from the zero-padded

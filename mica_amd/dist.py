@@ -5,7 +5,8 @@ the next round's compute, brings the cropped per-tile records to every rank; the
 volumes.
 
 Device-agnostic on purpose: `run_batch` and `stitch` are callables, so the rendezvous logic is
-exercised by world_size-2 gloo tests on CPU with a stand-in producer.
+exercised by world_size-2 gloo tests on CPU with a stand-in producer.  `RecordExchange` is the
+round-by-round form (`bench.py` times it step by step); `sharded_records` drives it over a whole map.
 """
 from __future__ import annotations
 
@@ -29,41 +30,81 @@ def rank_batches(T: int, batch: int, rank: int, world: int):
     return mine, rounds
 
 
+class RecordExchange:
+    """Double-buffered all-gather of fixed-size per-tile records.
+
+    post(r, rec, layout): this rank's records of round r ([count, *rec_shape] or None) go into send slot r&1 and the
+    all-gather of that slot starts (asynchronously on the collective's own stream with RCCL); then round r-1, whose
+    exchange ran beside this round's kernels, is handed to `stitch(records[count], first)` on `stitch_rank`
+    (None = every rank) for every rank's batch, in rank order.  `layout` = [(first, count)] per rank for round r.
+    flush() finishes the round still in flight.
+
+    xGMI moves ~0.2 GB per round at N = 8 - a few milliseconds that would otherwise sit between two 120-ms rounds on
+    every rank.  With the gloo backend and device tensors (rehearsing N > 1 on one GPU) the records are staged through
+    the host, synchronously."""
+
+    def __init__(self, batch: int, rec_shape, device, stitch, dtype=torch.float32, group=None, stitch_rank: int | None = 0):
+        self.group = group
+        on = dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.batch, self.stitch, self.stitch_rank = batch, stitch, stitch_rank
+        self.device = torch.device(device)
+        self.backend = dist.get_backend(group) if on else None
+        self.send = [torch.zeros((batch, *rec_shape), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = None
+        if self.world > 1:
+            # one flat receive buffer per slot: [world * batch, ...]; rank rr's records are rows rr*batch ...
+            self.recv = [torch.empty((self.world * batch, *rec_shape), dtype=dtype, device=device) for _ in range(2)]
+        self.pending = None
+
+    def _gather(self, slot):
+        if self.world == 1:
+            return None
+        if self.backend == "nccl":
+            return dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
+        if self.device.type == "cuda":                  # gloo rehearsal on a GPU: through the host
+            parts = [torch.empty(self.send[slot].shape, dtype=self.send[slot].dtype) for _ in range(self.world)]
+            dist.all_gather(parts, self.send[slot].cpu(), group=self.group)
+            self.recv[slot].copy_(torch.cat(parts))
+            return None
+        return dist.all_gather(list(self.recv[slot].chunk(self.world)), self.send[slot], group=self.group, async_op=True)
+
+    def _finish(self):
+        work, slot, layout = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()
+        if self.stitch_rank is None or self.rank == self.stitch_rank:
+            for rr, (first, count) in enumerate(layout):
+                if count:
+                    src = self.recv[slot][rr * self.batch:] if self.world > 1 else self.send[slot]
+                    self.stitch(src[:count], first)
+
+    def post(self, r: int, rec, layout):
+        slot = r & 1
+        if rec is not None and rec.shape[0]:
+            self.send[slot][:rec.shape[0]] = rec
+        work = self._gather(slot)
+        if self.pending is not None:
+            self._finish()
+        self.pending = (work, slot, layout)
+
+    def flush(self):
+        if self.pending is not None:
+            self._finish()
+
+
 def sharded_records(run_batch, stitch, T: int, batch: int, rec_shape, device, dtype=torch.float32, group=None,
                     stitch_rank: int | None = 0):
     """run_batch(first, count) -> tensor [count, *rec_shape] on `device`;
     stitch(records [count, *rec_shape], first) is called on `stitch_rank` (None = every rank) for every
     batch of every rank, in global tile order within a round."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    mine, rounds = rank_batches(T, batch, rank, world)
+    ex = RecordExchange(batch, rec_shape, device, stitch, dtype=dtype, group=group, stitch_rank=stitch_rank)
+    mine, rounds = rank_batches(T, batch, ex.rank, ex.world)
     plan = batch_plan(T, batch)
-    # Two send/receive slots: the all-gather of round r runs (async, on the collective's own stream) while round r+1
-    # computes; round r is stitched once its gather has landed.  xGMI moves ~0.2 GB per round at N = 8 - a few
-    # milliseconds that would otherwise sit between two 120-ms rounds on every rank.
-    send = [torch.zeros((batch, *rec_shape), dtype=dtype, device=device) for _ in range(2)]
-    recv = [[torch.empty_like(send[0]) for _ in range(world)] for _ in range(2)] if world > 1 else None
-
-    def finish(pend):
-        work, r, slot = pend
-        if work is not None:
-            work.wait()
-        if stitch_rank is None or rank == stitch_rank:
-            for rr in range(world):
-                k = r * world + rr
-                if k < len(plan):
-                    f, c = plan[k]
-                    stitch((recv[slot][rr] if world > 1 else send[slot])[:c], f)
-
-    pending = None
     for r, first, count in mine:
-        slot = r & 1
-        if count:
-            send[slot][:count] = run_batch(first, count)
-        work = dist.all_gather(recv[slot], send[slot], group=group, async_op=True) if world > 1 else None
-        if pending is not None:
-            finish(pending)
-        pending = (work, r, slot)
-    if pending is not None:
-        finish(pending)
+        layout = [plan[r * ex.world + rr] if r * ex.world + rr < len(plan) else (0, 0) for rr in range(ex.world)]
+        ex.post(r, run_batch(first, count) if count else None, layout)
+    ex.flush()
     return rounds

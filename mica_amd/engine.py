@@ -16,10 +16,6 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float32 or not t.is_cuda:
         raise MicaHipError(f"{name}: expected a float32 CUDA(HIP) tensor, got {t.dtype} on {t.device}")
@@ -37,14 +33,18 @@ class Engine:
         self.lib = _cabi.load_library()
         self.max_batch, self.tile_size = int(max_batch), int(tile_size)
         h = C.c_void_p()
-        torch.cuda.set_device(self.device)
-        r = self.lib.mica_create(self.device.index, self.max_batch, self.tile_size, C.byref(h))
+        with torch.cuda.device(self.device):          # the ambient current device of the caller is left alone
+            r = self.lib.mica_create(self.device.index, self.max_batch, self.tile_size, C.byref(h))
         if r != 0:
             raise MicaHipError(f"mica_create failed ({r}): {self.lib.mica_last_error(None).decode()}")
         self._h = h
         self.weights_loaded = False
 
     # -- plumbing -------------------------------------------------------------------------------
+    def _stream(self):
+        """torch's current stream of THIS engine's device (the C side does hipSetDevice(ctx->device))."""
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
     def _check(self, r, what):
         if r != 0:
             raise MicaHipError(f"{what} failed ({r}): {self.lib.mica_last_error(self._h).decode()}")
@@ -94,7 +94,7 @@ class Engine:
             b1 = min(B, b0 + self.max_batch)
             self._check(self.lib.mica_forward_logits(
                 self._h, _ptr(exp_map[b0:b1]), _ptr(af[b0:b1]) if af is not None else None, b1 - b0,
-                af_mode if af is not None else AF_NONE, _ptr(bb[b0:b1]), _ptr(ca[b0:b1]), _ptr(aa[b0:b1]), _stream()),
+                af_mode if af is not None else AF_NONE, _ptr(bb[b0:b1]), _ptr(ca[b0:b1]), _ptr(aa[b0:b1]), self._stream()),
                 "mica_forward_logits")
         return bb, ca, aa
 
@@ -116,7 +116,7 @@ class Engine:
             self._check(self.lib.mica_forward_tiles(
                 self._h, _ptr(map_tiles[b0:b1]), _ptr(af_tiles[b0:b1]) if af_tiles is not None else None, b1 - b0,
                 af_mode if af_tiles is not None else AF_NONE, _ptr(bbp[b0:b1]), _ptr(cap[b0:b1]), _ptr(aap[b0:b1]),
-                _ptr(pred[b0:b1]), _stream()), "mica_forward_tiles")
+                _ptr(pred[b0:b1]), self._stream()), "mica_forward_tiles")
         return out
 
     def postprocess(self, bb, ca, aa):
@@ -127,7 +127,7 @@ class Engine:
              torch.empty((B, S, S, S), dtype=torch.float32, device=self.device),
              torch.empty((B, 20, S, S, S), dtype=torch.float32, device=self.device),
              torch.empty((B, S, S, S), dtype=torch.float32, device=self.device))
-        self._check(self.lib.mica_postprocess(self._h, _ptr(bb), _ptr(ca), _ptr(aa), B, *[_ptr(t) for t in o], _stream()),
+        self._check(self.lib.mica_postprocess(self._h, _ptr(bb), _ptr(ca), _ptr(aa), B, *[_ptr(t) for t in o], self._stream()),
                     "mica_postprocess")
         return o
 
@@ -141,7 +141,7 @@ class Engine:
         W = grid + 2 * pad
         if out is None:
             out = torch.empty((count, Cc, W, W, W), dtype=torch.float32, device=self.device)
-        self._check(self.lib.mica_gather_tiles(self._h, _ptr(vol), Cc, n0, n1, n2, grid, pad, first, count, _ptr(out), _stream()),
+        self._check(self.lib.mica_gather_tiles(self._h, _ptr(vol), Cc, n0, n1, n2, grid, pad, first, count, _ptr(out), self._stream()),
                     "mica_gather_tiles")
         return out
 
@@ -153,14 +153,14 @@ class Engine:
         v4 = vol if vol.dim() == 4 else vol[None]
         Cc, n0, n1, n2 = v4.shape
         self._check(self.lib.mica_stitch_tiles(self._h, _ptr(tiles), Cc, n0, n1, n2, grid, pad, first, tiles.shape[0],
-                                               _ptr(v4), _stream()), "mica_stitch_tiles")
+                                               _ptr(v4), self._stream()), "mica_stitch_tiles")
         return vol
 
     def normalise_map_(self, vol: torch.Tensor):
         """In place; returns (median, percentile).  Raises MicaHipError like the reference logs failure."""
         vol = _f32c(vol, "vol")
         st = (C.c_double * 2)()
-        self._check(self.lib.mica_normalise_map(self._h, _ptr(vol), vol.numel(), st, _stream()), "mica_normalise_map")
+        self._check(self.lib.mica_normalise_map(self._h, _ptr(vol), vol.numel(), st, self._stream()), "mica_normalise_map")
         return float(st[0]), float(st[1])
 
     def zoom_cubic(self, vol: torch.Tensor, factors):
@@ -173,7 +173,7 @@ class Engine:
         if min(o) < 1:
             raise MicaHipError(f"zoom_cubic: empty output shape {o}")
         out = torch.empty(o, dtype=torch.float32, device=self.device)
-        self._check(self.lib.mica_zoom_cubic(self._h, _ptr(vol), *n, *o, _ptr(out), _stream()), "mica_zoom_cubic")
+        self._check(self.lib.mica_zoom_cubic(self._h, _ptr(vol), *n, *o, _ptr(out), self._stream()), "mica_zoom_cubic")
         return out
 
     def rasterise_atoms(self, xyz: torch.Tensor, bb: torch.Tensor, aa: torch.Tensor, origin, shape):
@@ -187,7 +187,7 @@ class Engine:
         nz, ny, nx = (int(v) for v in shape)
         out = torch.empty((24, nz, ny, nx), dtype=torch.float32, device=self.device)
         org = (C.c_float * 3)(*[float(np.float32(v)) for v in origin])
-        self._check(self.lib.mica_rasterise_atoms(self._h, _ptr(xyz), _ptr(bb), _ptr(aa), n, org, nz, ny, nx, _ptr(out), _stream()),
+        self._check(self.lib.mica_rasterise_atoms(self._h, _ptr(xyz), _ptr(bb), _ptr(aa), n, org, nz, ny, nx, _ptr(out), self._stream()),
                     "mica_rasterise_atoms")
         return out
 
@@ -200,7 +200,7 @@ class Engine:
         while True:
             idx = torch.empty((max(cap, 1),), dtype=torch.int64, device=self.device)
             cnt = (C.c_int64 * 1)()
-            self._check(self.lib.mica_threshold_points(self._h, _ptr(vol), n, float(thr), _ptr(idx), cap, cnt, _stream()),
+            self._check(self.lib.mica_threshold_points(self._h, _ptr(vol), n, float(thr), _ptr(idx), cap, cnt, self._stream()),
                         "mica_threshold_points")
             if cnt[0] <= cap:
                 return idx[:cnt[0]]
@@ -215,7 +215,7 @@ class Engine:
             raise MicaHipError("idx: expected an int64 CUDA(HIP) tensor")
         idx = idx.contiguous()
         out = torch.empty((c, idx.numel()), dtype=torch.float32, device=self.device)
-        self._check(self.lib.mica_gather_values(self._h, _ptr(vol), c, nvox, _ptr(idx), idx.numel(), _ptr(out), _stream()),
+        self._check(self.lib.mica_gather_values(self._h, _ptr(vol), c, nvox, _ptr(idx), idx.numel(), _ptr(out), self._stream()),
                     "mica_gather_values")
         return out if vol.dim() == 4 else out[0]
 
@@ -232,7 +232,7 @@ class Engine:
         aao = torch.empty((n, 20), dtype=torch.float32, device=self.device)
         ok = torch.empty((n,), dtype=torch.int32, device=self.device)
         self._check(self.lib.mica_refine_candidates(self._h, _ptr(ca), _ptr(aa), *ca.shape, _ptr(cands), n, _ptr(coord), _ptr(aao),
-                                                    _ptr(ok), _stream()), "mica_refine_candidates")
+                                                    _ptr(ok), self._stream()), "mica_refine_candidates")
         return coord, aao, ok.bool()
 
     # -- single ops (tests) -----------------------------------------------------------------------------
@@ -244,14 +244,14 @@ class Engine:
         cout = w.shape[0]
         y = torch.empty((B, cout, d, h, ww), dtype=torch.float32, device=self.device)
         self._check(self.lib.mica_op_conv3d(self._h, _ptr(x), B, cin, d, h, ww, w.ctypes.data_as(_cabi._FP),
-                                            b.ctypes.data_as(_cabi._FP), cout, k, _ptr(y), _stream()), "mica_op_conv3d")
+                                            b.ctypes.data_as(_cabi._FP), cout, k, _ptr(y), self._stream()), "mica_op_conv3d")
         return y
 
     def op_instnorm_relu(self, x):
         x = _f32c(x, "x")
         B, c, d, h, w = x.shape
         y = torch.empty_like(x)
-        self._check(self.lib.mica_op_instnorm_relu(self._h, _ptr(x), B, c, d, h, w, _ptr(y), _stream()), "mica_op_instnorm_relu")
+        self._check(self.lib.mica_op_instnorm_relu(self._h, _ptr(x), B, c, d, h, w, _ptr(y), self._stream()), "mica_op_instnorm_relu")
         return y
 
     def op_depthwise3(self, x, w, b):
@@ -261,14 +261,14 @@ class Engine:
         b = np.ascontiguousarray(b, dtype=np.float32)
         y = torch.empty_like(x)
         self._check(self.lib.mica_op_depthwise3(self._h, _ptr(x), B, c, d, h, ww, w.ctypes.data_as(_cabi._FP),
-                                                b.ctypes.data_as(_cabi._FP), _ptr(y), _stream()), "mica_op_depthwise3")
+                                                b.ctypes.data_as(_cabi._FP), _ptr(y), self._stream()), "mica_op_depthwise3")
         return y
 
     def op_stem(self, m):
         m = _f32c(m, "map")
         B, one, d, h, w = m.shape
         y = torch.empty((B, 128, d, h, w), dtype=torch.float32, device=self.device)
-        self._check(self.lib.mica_op_stem(self._h, _ptr(m), B, d, h, w, _ptr(y), _stream()), "mica_op_stem")
+        self._check(self.lib.mica_op_stem(self._h, _ptr(m), B, d, h, w, _ptr(y), self._stream()), "mica_op_stem")
         return y
 
     def set_profiling(self, on: bool):

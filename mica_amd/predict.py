@@ -14,14 +14,22 @@ import numpy as np
 import torch
 
 from .dataset import CryoEMTestDataset
-from .engine import AF_PER_TILE, Engine
+from .engine import AF_BATCH, AF_PER_TILE, Engine
 from .weights import load_checkpoint_state_dict
 
 KEYS = ("backbone_probability", "carbon_alpha_probability", "amino_acid_prediction", "amino_acid_probability")
 
 
 class CryoEMPredictor:
-    def __init__(self, model_path, grids_path, output_path, save_output=True, device="cuda", quiet=False, batch_size=8):
+    def __init__(self, model_path, grids_path, output_path, save_output=True, device="cuda", quiet=False, batch_size=8,
+                 reference_batching=False):
+        """Same positional arguments as the reference (utils/predict.py:48).  Two additions:
+        `batch_size` - tiles per forward call (results do not depend on it with per-tile gating);
+        `reference_batching` - reproduce the reference's batching exactly (utils/predict.py:176-215, 278-286): batch 1
+        up to `batch_threshold` tiles (= per-tile AF3 gating), above it batches of `optimal_batch_size` (at most 8) tiles in
+        glob order with the AF3 test of models/model.py:60 taken over the WHOLE batch, so that a tile without atoms that
+        shares a batch with one that has atoms goes through feat_conv/fusion as it does in the reference.  The default
+        (False) gates per tile: results independent of file order and batch size."""
         self.model_path = model_path
         self.grids_path = grids_path
         self.output_path = output_path
@@ -30,6 +38,10 @@ class CryoEMPredictor:
         self.device = device
         self.quiet = quiet
         self.batch_size = batch_size
+        self.reference_batching = bool(reference_batching)
+        self.batch_threshold = 200          # utils/predict.py:72 (an instance attribute there too)
+        self.use_optimized_batching = False
+        self.optimal_batch_size = 1
         self.engine = None
         self.sample_count = 0
         self.timing_stats = {k: 0 for k in ('strategy_selection', 'model_loading', 'data_loading', 'inference',
@@ -49,6 +61,10 @@ class CryoEMPredictor:
         if not files:
             self.logger.error(f"No grid files found in: {self.grids_path}/normalized_map_grids/")
             return False
+        # utils/predict.py:193-199.  _calculate_optimal_batch_size (:156-174) = min(8, 70 % of device memory minus 3x the
+        # model over 31 MB per sample): with 288 GB of HBM that is always the cap of 8
+        self.use_optimized_batching = self.sample_count > self.batch_threshold
+        self.optimal_batch_size = 8 if self.use_optimized_batching else 1
         return True
 
     def load_model(self, tile_size=64):
@@ -61,7 +77,7 @@ class CryoEMPredictor:
                 raise RuntimeError("device='cpu': this build runs on MI355X only (no CPU path)")
             sd = load_checkpoint_state_dict(self.model_path)
             dev = torch.device(self.device if ":" in str(self.device) else "cuda:0")
-            self.engine = Engine(dev, max_batch=self.batch_size, tile_size=tile_size)
+            self.engine = Engine(dev, max_batch=max(self.batch_size, 8) if self.reference_batching else self.batch_size, tile_size=tile_size)
             self.engine.load_state_dict(sd)
             self.timing_stats['model_loading'] = time.time() - t0
             return True
@@ -95,9 +111,24 @@ class CryoEMPredictor:
             order = sorted(range(len(meta)), key=lambda t: ((meta[t][0] // grid) * nt1 + meta[t][1] // grid) * nt2 + meta[t][2] // grid)
             tindex = lambda t: ((meta[t][0] // grid) * nt1 + meta[t][1] // grid) * nt2 + meta[t][2] // grid
             out = torch.zeros((23, *shape), dtype=torch.float32, device=e.device)
-            B = self.batch_size
+            B = e.max_batch
             rec = torch.empty((B, 23, S, S, S), dtype=torch.float32, device=e.device)
             pos = 0
+            if self.reference_batching and self.use_optimized_batching:
+                # the reference's DataLoader: consecutive files in glob order, batch-wide AF3 gate (model.py:60)
+                bs = self.optimal_batch_size
+                for g0 in range(0, len(meta), bs):
+                    grp = list(range(g0, min(g0 + bs, len(meta))))
+                    items = [dataset[t] for t in grp]
+                    x = torch.from_numpy(np.stack([it[0] for it in items])).to(e.device)
+                    af = torch.from_numpy(np.stack([it[1] for it in items])).to(e.device)
+                    n = len(grp)
+                    bbp, cap, aap, pred = e.forward_tiles(x.view(n, S, S, S), af, af_mode=AF_BATCH)
+                    rec[:n, 0], rec[:n, 1], rec[:n, 2] = bbp, cap, pred
+                    rec[:n, 3:] = aap
+                    for q, t in enumerate(grp):
+                        e.stitch_tiles(rec[q:q + 1], out, grid, pad, tindex(t))
+                pos = len(order)
             while pos < len(order):
                 run = [order[pos]]
                 while len(run) < B and pos + len(run) < len(order) and tindex(order[pos + len(run)]) == tindex(run[-1]) + 1:

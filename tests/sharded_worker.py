@@ -1,0 +1,39 @@
+"""One rank of the 2-rank rehearsal of BASELINE configs[2] on a single GPU (started by tests/test_gpu_configs.py as a
+fresh child process; gloo rendezvous on 127.0.0.1, every rank on cuda:0): runs VolumePredictor.predict_volume_sharded
+with the real engine; rank 0 writes the four volumes."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_path, shape, batch = sys.argv[1], tuple(int(v) for v in sys.argv[2].split("x")), int(sys.argv[3])
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from mica_amd.engine import Engine
+    from mica_amd.pipeline import VolumePredictor
+    from mica_amd.synth import synth_af, synth_density
+    from mica_amd.weights import synth_state_dict
+
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    eng = Engine(0, max_batch=batch, tile_size=64)
+    eng.load_state_dict(synth_state_dict(2022))
+    vol = torch.from_numpy(synth_density(shape, 91)).cuda()
+    af = torch.from_numpy(synth_af(shape, 91, 2e-3)).cuda()
+    af[:, :, :, : shape[2] // 2] = 0                       # some tiles see no atoms: per-tile gating on every rank
+    out = VolumePredictor(eng, 48, 8, batch).predict_volume_sharded(vol, af)
+    if dist.get_rank() == 0:
+        np.savez(out_path, **{k: v.cpu().numpy() for k, v in out.items()})
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

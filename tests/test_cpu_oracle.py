@@ -186,7 +186,7 @@ def test_product_never_imports_oracle():
 
 
 def test_inline_asm_weight_prefetch_is_hazard_free(tmp_path):
-    """conv_wino_kernel fetches its weight fragments with inline-asm loads and hand-counted s_waitcnt.  hipcc does not
+    """conv_wino16_kernel fetches its weight fragments with inline-asm loads and hand-counted s_waitcnt.  hipcc does not
     model those loads, so the emitted code is audited: between an asm load and the wait that retires it no other
     instruction may touch its destination registers (tools/audit_asm_loads.py); cross-compiles without a GPU."""
     import shutil
@@ -199,18 +199,7 @@ def test_inline_asm_weight_prefetch_is_hazard_free(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", asm, src],
                           stderr=subprocess.DEVNULL)
     text = open(asm).read()
-    found = 0
-    for variant, keep in (("ILi128ELi2E", 8), ("ILi64ELi2E", 16), ("ILi32ELi1E", 16)):
-        m = re.search(r"^_ZN4mica16conv_wino_kernel" + variant + r".*?s_endpgm", text, flags=re.S | re.M)
-        assert m, variant
-        part = str(tmp_path / (variant + ".s"))
-        open(part, "w").write(m.group(0))
-        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), part, str(keep)], text=True)
-        assert "violations: 0" in out, out[-2000:]
-        assert m.group(0).count("global_load_dwordx4") >= 18 and ".vgpr_spill_count" not in m.group(0)
-        found += 1
-    assert found == 3
-    # the persistent 16x16x32 variants: same audit with their LDS-DMA instructions occupying queue slots.  Per chunk and wave the
+    # the persistent 16x16x32 variants: the audit models their LDS-DMA instructions as occupying queue slots.  Per chunk and wave the
     # 128-channel variant walks 14 steps (448 MFMAs; 9 waits that leave the previous step's one DMA in flight, 5 + 1 plain
     # ones), the 64-channel variant 7 steps (224 MFMAs; previous step issued 2, 1 or 0 DMAs), the 32-channel variant 7 steps of
     # two column tiles (112 MFMAs, two weight loads per step); one copy of the chunk body each
