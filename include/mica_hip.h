@@ -146,6 +146,14 @@ int mica_op_depthwise3(mica_ctx* ctx, const float* d_x, int batch, int c, int d,
  * Uses the ctx's loaded input_processing.exp_convs.* weights.                                 */
 int mica_op_stem(mica_ctx* ctx, const float* d_map, int batch, int d, int h, int w, float* d_y, void* stream);
 
+/* Activation scale of the split-f16 operand encoding (x * scale = hi + lo in f16): 16 after mica_create.  When an
+ * activation exceeds the f16 range at the current scale (|x| > 60000 / scale, i.e. 3750 at 16) mica_forward_* repeat the
+ * forward at scale / 16 - exact: powers of two, undone in the conv epilogues - and the context keeps the lower scale;
+ * only NaN/Inf, or |x| > 1.5e7 (scale 2^-8), end in MICA_ERR_RANGE.  The reference (fp32 PyTorch) has no such limit.
+ * The setter takes a power of two in [2^-8, 16] (tests; or to return to 16 after an outlier map).                  */
+float mica_get_activation_scale(const mica_ctx* ctx);
+int mica_set_activation_scale(mica_ctx* ctx, float scale);
+
 /* ---- introspection for bench.py ----------------------------------------------------------- */
 /* Times (ms, HIP events on `stream`) of the dense-conv launches of the last forward when
  * profiling was enabled with mica_set_profiling(ctx, 1): sum and launch count.               */

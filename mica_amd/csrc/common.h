@@ -9,11 +9,20 @@ namespace mica {
 // ---- activation formats ----------------------------------------------------------------------
 // raw   : float  [B][V][C]              (NDHWC, V = D*H*W voxels)
 // split : _Float16 [B][chunks][V][2][16]  a 16-channel chunk of one voxel is 64 B: 16 "hi" halves
-//         then 16 "lo" halves with  x * ASCALE = hi + lo (+ ~2^-22 relative).  This is what the
+//         then 16 "lo" halves with  x * ascale = hi + lo (+ ~2^-22 relative).  This is what the
 //         MFMA conv consumes: three f16 MFMAs (hi*hi, hi*lo, lo*hi) give ~fp32 products.
-constexpr float ASCALE = 16.0f;          // activation pre-scale (keeps `lo` out of f16 subnormals)
-constexpr float INV_ASCALE = 1.0f / 16.0f;
-constexpr float F16_LIMIT = 60000.0f;    // |x*ASCALE| above this sets the range-error flag
+// `ascale` is a power of two carried by the context: 16 by default (keeps `lo` out of f16 subnormals for |x| >= 2^-7);
+// when an activation overflows the f16 range at that scale (|x| > 3750) the forward is repeated with ascale / 16
+// (forward.hip: forward_checked), down to 2^-8 (|x| < 1.5e7).  Scaling by a power of two is exact, and the conv epilogues
+// undo it (out_scale = 1 / (wscale * ascale)).
+constexpr float ASCALE_DEFAULT = 16.0f;
+constexpr float ASCALE_MIN = 1.0f / 256.0f;
+constexpr float F16_LIMIT = 60000.0f;    // |x*ascale| above this sets the range flag
+constexpr int RANGE_OVERFLOW = 1, RANGE_NONFINITE = 2;      // bits of the range flag
+struct SplitEnc {           // where the split encoders report and how they scale
+    int* err;               // device flag, OR of RANGE_* bits
+    float ascale;
+};
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -42,8 +51,7 @@ struct Dims { int D, H, W; };  // one tile
 // wpk_bstride = halves between batch entries (0 = shared).  out raw f32 [B][V][Cout]:
 // out = acc * out_scale + bias.
 void launch_conv_mfma(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
-                      float out_scale, float* out, int B, Dims d, int cout, int ksize, int* errflag,
-                      hipStream_t st);
+                      float out_scale, float* out, int B, Dims d, int cout, int ksize, hipStream_t st);
 // Pack torch-layout conv weights into wpk.  seg_c/seg_cp: per-source real and padded channel counts.
 // cin_scale f32[B][Cin] (nullable) multiplies input channels (gate folding); cout_scale scalar.
 void launch_pack_weights(const float* w, int cout, int cin, int ksize, const int* h_seg_c, const int* h_seg_cp,
@@ -57,10 +65,10 @@ void launch_stats(const float* x, int B, int V, int C, float eps, float* mean, f
 int64_t stats_ws_floats(int B, int C);
 // y = relu?((x-mean)*rstd) * scale ; writes split view and/or raw f32 ; optional per (b,c) mean of y (gap)
 void launch_prep(const float* x, int B, int V, int C, const float* mean, const float* rstd, int relu,
-                 const float* scale, SplitView out, float* out_raw, float* gap, float* ws, int* errflag,
+                 const float* scale, SplitView out, float* out_raw, float* gap, float* ws, SplitEnc enc,
                  hipStream_t st);
 // NCDHW f32 [B][C][V] -> split (C padded to 16, zero filled) ; also per-batch |x| sum
-void launch_prep_ncdhw(const float* x, int B, int V, int C, SplitView out, float* abs_sum, int* errflag,
+void launch_prep_ncdhw(const float* x, int B, int V, int C, SplitView out, float* abs_sum, SplitEnc enc,
                        hipStream_t st);
 void launch_finalize_sum(const float* ws, int B, int nblocks, int C, float inv, float* out, hipStream_t st);
 void launch_nchw_to_nhwc(const float* x, int B, int C, int V, float* y, hipStream_t st);
@@ -82,21 +90,21 @@ void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, floa
 int64_t fused_stats_ws_floats(int B, int tile_size);
 // stem: map f32 [B][V] -> split view of 128 channels + gap[b][128] (mean over voxels)
 void launch_stem(const float* map, int B, Dims d, const float* wstem, const float* bstem, SplitView out,
-                 float* out_raw, float* gap, float* ws, hipStream_t st);
+                 float* out_raw, float* gap, float* ws, float ascale, hipStream_t st);
 int64_t stem_weight_floats();
 // x_feat raw [B][V][64] -> split(x_feat * sigmoid(w2 . relu(W0 x + b0) + b2))
 void launch_feat_gate(const float* x, int B, int V, const float* w0, const float* b0, const float* w2,
-                      const float* b2, SplitView out, int* errflag, hipStream_t st);
-// head tail: raw2 [B][V][32] -> logits NCDHW [B][ncls][V] ; optional copy into split extras view at ch_off
+                      const float* b2, SplitView out, SplitEnc enc, hipStream_t st);
+// head tail: raw2 [B][V][32] -> logits NCDHW [B][ncls][V]
 // extra_raw (nullable): also store the logits as channels [extra_ch_off, +ncls) of f32 [B][extra_raw_c][V]
 void launch_head_final(const float* x, int B, int V, const float* mean, const float* rstd, const float* gate,
-                       const float* wf, const float* bf, int ncls, float* logits, SplitView extra,
-                       int extra_ch_off, float* extra_raw, int extra_raw_c, hipStream_t st);
+                       const float* wf, const float* bf, int ncls, float* logits, int extra_ch_off, float* extra_raw,
+                       int extra_raw_c, hipStream_t st);
 // ---- Winograd F(2,3) along x (dense 3^3 convs): operand layout [B][chunks][4 p][4 q][Vh][8], Vh = D*H*ceil(W/2)
 void launch_prep_wino(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, int relu,
-                      const float* scale, SplitView wino, SplitView plain, float* gap, float* ws, int* errflag,
+                      const float* scale, SplitView wino, SplitView plain, float* gap, float* ws, SplitEnc enc,
                       hipStream_t st);
-void launch_prep_ncdhw_wino(const float* x, int B, Dims d, int C, SplitView wino, int* errflag, hipStream_t st);
+void launch_prep_ncdhw_wino(const float* x, int B, Dims d, int C, SplitView wino, SplitEnc enc, hipStream_t st);
 int launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
                      float out_scale, float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st);
 void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_seg_c, const int* h_seg_cp, int nseg,

@@ -90,6 +90,7 @@ struct mica_ctx {
     float* ws = nullptr;          // reduction partials
     float *v_mean, *v_rstd, *v_mean3, *v_rstd3, *v_pool, *v_gse, *v_gate, *v_abs;
     int* d_err = nullptr;
+    float ascale = ASCALE_DEFAULT;   // activation scale of the split encoding (common.h); lowered by forward_checked on overflow
     float* h_abs = nullptr;       // pinned
     int* h_err = nullptr;         // pinned
 
@@ -259,11 +260,11 @@ void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, 
     prof_begin(c, pk, st);
     int P = 0;
     if (L.wino)
-        P = launch_conv_wino(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
+        P = launch_conv_wino(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * c->ascale), out, B, c->d, L.cout,
                              mean ? c->ws : nullptr, st);
     else
-        launch_conv_mfma(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * ASCALE), out, B, c->d, L.cout,
-                         L.k, c->d_err, st);
+        launch_conv_mfma(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * c->ascale), out, B, c->d, L.cout,
+                         L.k, st);
     prof_end(c, pk, L.flops_per_voxel * (double)c->V * B, st);
     if (mean) {
         if (L.wino) launch_stats_finalize(c->ws, B, P, L.cout, 1e-5f, mean, rstd, st);
@@ -285,9 +286,9 @@ void make_operand(mica_ctx* c, const float* raw, int B, int C, const float* mean
     const double bytes = (double)B * c->V * C * (4.0 + (t3.p ? 8.0 : 0.0) + (t1.p ? 4.0 : 0.0));
     struct End { mica_ctx* c; double b; hipStream_t s; ~End() { prof_end(c, 3, b, s); } } end_{c, bytes, st};
     if (t3.p) {
-        launch_prep_wino(raw, B, c->d, C, mean, rstd, relu, nullptr, t3, t1, gap, c->ws, c->d_err, st);
+        launch_prep_wino(raw, B, c->d, C, mean, rstd, relu, nullptr, t3, t1, gap, c->ws, SplitEnc{c->d_err, c->ascale}, st);
     } else {
-        launch_prep(raw, B, c->V, C, mean, rstd, relu, nullptr, t1, nullptr, gap, c->ws, c->d_err, st);
+        launch_prep(raw, B, c->V, C, mean, rstd, relu, nullptr, t1, nullptr, gap, c->ws, SplitEnc{c->d_err, c->ascale}, st);
     }
 }
 
@@ -298,15 +299,15 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
     const Dims d = c->d;
     SplitView none{nullptr, 0, 0, 0};
     // ---- MultiScaleInput (model.py:43-74) ------------------------------------------------------
-    launch_stem(d_map, B, d, c->stem_w, c->stem_b, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, c->ws, st);
+    launch_stem(d_map, B, d, c->stem_w, c->stem_b, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, c->ws, c->ascale, st);
     if (!use_af) {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->downsizing.d_cin_scale, 128, st);
         run_conv(c, c->downsizing, SrcList().add(c->S_exp, 8, 0, 8), c->R_a, B, st);
     } else {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->fusion0.d_cin_scale, 192, st);
-        launch_prep_ncdhw_wino(d_af, B, d, 24, view(c->S_af, 2, 0, 2), c->d_err, st);
+        launch_prep_ncdhw_wino(d_af, B, d, 24, view(c->S_af, 2, 0, 2), SplitEnc{c->d_err, c->ascale}, st);
         run_conv(c, c->feat_conv, SrcList().add(c->S_af, 2, 0, 2), c->R_b, B, st);
-        launch_feat_gate(c->R_b, B, V, c->fg_w0, c->fg_b0, c->fg_w2, c->fg_b2, view(c->S_fw, 4, 0, 4), c->d_err, st);
+        launch_feat_gate(c->R_b, B, V, c->fg_w0, c->fg_b0, c->fg_w2, c->fg_b2, view(c->S_fw, 4, 0, 4), SplitEnc{c->d_err, c->ascale}, st);
         run_conv(c, c->fusion0, SrcList().add(c->S_exp, 8, 0, 8).add(c->S_fw, 4, 0, 4), c->R_a, B, st);
     }
     make_operand(c, c->R_a, B, 64, nullptr, nullptr, 0, view(c->S_x0, 4, 0, 4), none, nullptr, st);
@@ -363,12 +364,12 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         run_conv(c, H.conv1, src, c->R_a, B, st, c->v_mean, c->v_rstd);
         make_operand(c, c->R_a, B, 64, c->v_mean, c->v_rstd, 1, view(c->S_h1, 4, 0, 4), none, nullptr, st);
         run_conv(c, H.conv2, SrcList().add(c->S_h1, 4, 0, 4), c->R_b, B, st, c->v_mean, c->v_rstd);
-        launch_prep(c->R_b, B, V, 32, c->v_mean, c->v_rstd, 1, nullptr, none, nullptr, c->v_pool, c->ws, c->d_err, st);
+        launch_prep(c->R_b, B, V, 32, c->v_mean, c->v_rstd, 1, nullptr, none, nullptr, c->v_pool, c->ws, SplitEnc{c->d_err, c->ascale}, st);
         gate(c, H.cal, c->v_pool, nullptr, B, nullptr, c->v_gate, nullptr, 0, st);
         const bool feeds = h < 2;
-        launch_head_final(c->R_b, B, V, c->v_mean, c->v_rstd, c->v_gate, H.wf, H.bf, H.ncls, outs[h], none, 4 * h,
+        launch_head_final(c->R_b, B, V, c->v_mean, c->v_rstd, c->v_gate, H.wf, H.bf, H.ncls, outs[h], 4 * h,
                           feeds ? c->extra_raw : nullptr, 8, st);
-        if (feeds) launch_prep_ncdhw_wino(c->extra_raw, B, d, 8, view(c->S_extra, 1, 0, 1), c->d_err, st);
+        if (feeds) launch_prep_ncdhw_wino(c->extra_raw, B, d, 8, view(c->S_extra, 1, 0, 1), SplitEnc{c->d_err, c->ascale}, st);
     }
     return MICA_OK;
 }
@@ -388,7 +389,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     if (d_af && af_mode != MICA_AF_NONE) {
         // is_af_zero = af.abs().sum() < 1e-6  (model.py:60): device reduction, one small D2H per call
         HIPC(c, hipMemsetAsync(c->v_abs, 0, sizeof(float) * B, st));
-        launch_prep_ncdhw(d_af, B, V, 24, SplitView{nullptr, 0, 0, 0}, c->v_abs, c->d_err, st);
+        launch_prep_ncdhw(d_af, B, V, 24, SplitView{nullptr, 0, 0, 0}, c->v_abs, SplitEnc{c->d_err, c->ascale}, st);
         HIPC(c, hipMemcpyAsync(c->h_abs, c->v_abs, sizeof(float) * B, hipMemcpyDeviceToHost, st));
         HIPC(c, hipStreamSynchronize(st));
         if (af_mode == MICA_AF_BATCH) {
@@ -441,15 +442,26 @@ bool pow2_8_512(int c) { return c >= 8 && c <= 512 && (c & (c - 1)) == 0; }
 }  // namespace
 
 
-// range check of the split-f16 encoding: fail loudly rather than return clipped activations (synchronises `st`)
-static int check_range(mica_ctx* c, hipStream_t st) {
-    HIPC(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPC(c, hipStreamSynchronize(st));
-    if (*c->h_err) {
-        c->err = "activation outside the representable range of the split-f16 conv path (|x| > 3750, or NaN/Inf in the input)";
-        return MICA_ERR_RANGE;
+// The forward with the range check of the split-f16 encoding (synchronises `st`).  An activation beyond the f16 range at
+// the current activation scale (|x| * ascale > 60000) repeats the forward at ascale / 16 - exact, the epilogues undo the
+// power of two - and the lower scale stays with the context; NaN/Inf, or an overflow at the smallest scale, fail loudly
+// with MICA_ERR_RANGE rather than return clipped numbers.
+static int forward_checked(mica_ctx* c, const float* d_map, const float* d_af, int B, int af_mode, float* o_bb, float* o_ca,
+                           float* o_aa, hipStream_t st) {
+    for (;;) {
+        int r = forward_impl(c, d_map, d_af, B, af_mode, o_bb, o_ca, o_aa, st);
+        if (r) return r;
+        HIPC(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPC(c, hipStreamSynchronize(st));
+        const int flag = *c->h_err;
+        if (!flag) return MICA_OK;
+        if ((flag & RANGE_NONFINITE) || c->ascale <= ASCALE_MIN) {
+            c->err = (flag & RANGE_NONFINITE) ? "activation outside the representable range of the split-f16 conv path: NaN/Inf in the input or in an activation"
+                                              : "activation outside the representable range of the split-f16 conv path (|x| > 1.5e7)";
+            return MICA_ERR_RANGE;
+        }
+        c->ascale *= 1.0f / 16.0f;
     }
-    return MICA_OK;
 }
 
 // =================================================================================================
@@ -646,9 +658,7 @@ int mica_forward_logits(mica_ctx* c, const float* d_map, const float* d_af, int 
                         float* d_aa, void* stream) {
     if (!c) return MICA_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int r = forward_impl(c, d_map, d_af, batch, af_mode, d_bb, d_ca, d_aa, st);
-    if (r) return r;
-    return check_range(c, st);
+    return forward_checked(c, d_map, d_af, batch, af_mode, d_bb, d_ca, d_aa, st);
 }
 
 int mica_postprocess(mica_ctx* c, const float* d_bb, const float* d_ca, const float* d_aa, int batch, float* d_bb_prob,
@@ -665,11 +675,9 @@ int mica_forward_tiles(mica_ctx* c, const float* d_map, const float* d_af, int b
                        float* d_ca_prob, float* d_aa_prob, float* d_aa_pred, void* stream) {
     if (!c) return MICA_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int r = forward_impl(c, d_map, d_af, batch, af_mode, c->logits[0], c->logits[1], c->logits[2], st);
+    int r = forward_checked(c, d_map, d_af, batch, af_mode, c->logits[0], c->logits[1], c->logits[2], st);
     if (r) return r;
-    r = mica_postprocess(c, c->logits[0], c->logits[1], c->logits[2], batch, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, stream);
-    if (r) return r;
-    return check_range(c, st);
+    return mica_postprocess(c, c->logits[0], c->logits[1], c->logits[2], batch, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, stream);
 }
 
 int64_t mica_tile_count(int64_t n0, int64_t n1, int64_t n2, int grid) {
@@ -841,13 +849,13 @@ int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int
     ConvSrcs s{};
     s.n = 1; s.p[0] = sx; s.chunks_total[0] = cp / 16; s.chunk_off[0] = 0; s.chunks[0] = cp / 16;
     if (wino) {
-        launch_prep_ncdhw_wino(d_x, batch, Dims{d, h, w}, cin, SplitView{sx, cp / 16, 0, cp / 16}, derr, st);
+        launch_prep_ncdhw_wino(d_x, batch, Dims{d, h, w}, cin, SplitView{sx, cp / 16, 0, cp / 16}, SplitEnc{derr, ASCALE_DEFAULT}, st);
         launch_pack_weights_wino(dw, cout, cin, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
-        launch_conv_wino(s, pk, 0, db, 1.0f / (ws * ASCALE), raw, batch, Dims{d, h, w}, cout, nullptr, st);
+        launch_conv_wino(s, pk, 0, db, 1.0f / (ws * ASCALE_DEFAULT), raw, batch, Dims{d, h, w}, cout, nullptr, st);
     } else {
-        launch_prep_ncdhw(d_x, batch, V, cin, SplitView{sx, cp / 16, 0, cp / 16}, nullptr, derr, st);
+        launch_prep_ncdhw(d_x, batch, V, cin, SplitView{sx, cp / 16, 0, cp / 16}, nullptr, SplitEnc{derr, ASCALE_DEFAULT}, st);
         launch_pack_weights(dw, cout, cin, k, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
-        launch_conv_mfma(s, pk, 0, db, 1.0f / (ws * ASCALE), raw, batch, Dims{d, h, w}, cout, k, derr, st);
+        launch_conv_mfma(s, pk, 0, db, 1.0f / (ws * ASCALE_DEFAULT), raw, batch, Dims{d, h, w}, cout, k, st);
     }
     launch_nhwc_to_nchw(raw, batch, cout, V, d_y, st);
     HIPC(c, hipGetLastError());
@@ -871,7 +879,7 @@ int mica_op_instnorm_relu(mica_ctx* c, const float* d_x, int batch, int ch, int 
     if (!a || !b || !mean || !rstd || !ws || !derr) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
     launch_stats(a, batch, V, ch, 1e-5f, mean, rstd, ws, st);
-    launch_prep(a, batch, V, ch, mean, rstd, 1, nullptr, SplitView{nullptr, 0, 0, 0}, b, nullptr, ws, derr, st);
+    launch_prep(a, batch, V, ch, mean, rstd, 1, nullptr, SplitView{nullptr, 0, 0, 0}, b, nullptr, ws, SplitEnc{derr, ASCALE_DEFAULT}, st);
     launch_nhwc_to_nchw(b, batch, ch, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));
@@ -917,10 +925,23 @@ int mica_op_stem(mica_ctx* c, const float* d_map, int batch, int d, int h, int w
     Tmp t;
     float* raw = t.get<float>((int64_t)batch * V * 128);
     if (!raw) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
-    launch_stem(d_map, batch, Dims{d, h, w}, c->stem_w, c->stem_b, SplitView{nullptr, 0, 0, 0}, raw, nullptr, nullptr, st);
+    launch_stem(d_map, batch, Dims{d, h, w}, c->stem_w, c->stem_b, SplitView{nullptr, 0, 0, 0}, raw, nullptr, nullptr, ASCALE_DEFAULT, st);
     launch_nhwc_to_nchw(raw, batch, 128, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));
+    return MICA_OK;
+}
+
+float mica_get_activation_scale(const mica_ctx* c) { return c ? c->ascale : 0.f; }
+
+int mica_set_activation_scale(mica_ctx* c, float scale) {
+    if (!c) return MICA_ERR_ARG;
+    int e = 0;
+    if (!(scale >= ASCALE_MIN && scale <= ASCALE_DEFAULT) || std::frexp(scale, &e) != 0.5f) {
+        c->err = "mica_set_activation_scale: a power of two in [2^-8, 16] expected";
+        return MICA_ERR_ARG;
+    }
+    c->ascale = scale;
     return MICA_OK;
 }
 

@@ -882,7 +882,7 @@ void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_se
 }
 
 void launch_conv_mfma(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
-                      float out_scale, float* out, int B, Dims d, int cout, int ksize, int* /*errflag*/,
+                      float out_scale, float* out, int B, Dims d, int cout, int ksize,
                       hipStream_t st) {
     // the 1x1x1 convs (3^3 goes through launch_conv_wino); cout is always a multiple of 32 here (small heads go through
     // launch_head_final)
@@ -1211,7 +1211,7 @@ __device__ __forceinline__ void stem_one(const float* __restrict__ tile, const f
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ map, Dims d,
                                                    const float* __restrict__ wstem, const float* __restrict__ bstem,
                                                    SplitView out, float* __restrict__ out_raw,
-                                                   float* __restrict__ ws, int ntx, int nty) {
+                                                   float* __restrict__ ws, int ntx, int nty, float ascale) {
     __shared__ float tile[ST_LZ * ST_LY * ST_LX];
     __shared__ float csum[4][128];   // per-wave partial channel sums (fixed summation order => deterministic)
     const int tid = threadIdx.x, b = blockIdx.y;
@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ map
                         half8 hi[2], lo[2];
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
-                            float xs = acc[v][cc * 16 + j] * ASCALE;
+                            float xs = acc[v][cc * 16 + j] * ascale;
                             _Float16 h = (_Float16)xs;
                             hi[j >> 3][j & 7] = h;
                             lo[j >> 3][j & 7] = (_Float16)(xs - (float)h);
@@ -1292,10 +1292,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ map
 }
 
 void launch_stem(const float* map, int B, Dims d, const float* wstem, const float* bstem, SplitView out,
-                 float* out_raw, float* gap, float* ws, hipStream_t st) {
+                 float* out_raw, float* gap, float* ws, float ascale, hipStream_t st) {
     int ntx = (d.W + ST_X - 1) / ST_X, nty = (d.H + ST_Y - 1) / ST_Y, ntz = (d.D + ST_Z - 1) / ST_Z;
     dim3 grid(ntx * nty * ntz, B);
-    hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, st, map, d, wstem, bstem, out, out_raw, gap ? ws : nullptr, ntx, nty);
+    hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, st, map, d, wstem, bstem, out, out_raw, gap ? ws : nullptr, ntx, nty, ascale);
     if (gap) launch_finalize_sum(ws, B, (int)grid.x, 128, 1.0f / (float)(d.D * d.H * d.W), gap, st);
 }
 

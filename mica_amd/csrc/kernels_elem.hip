@@ -172,11 +172,11 @@ void launch_finalize_sum(const float* ws, int B, int nblocks, int C, float inv, 
 // prep: y = relu?((x - mean) * rstd) * scale  ->  split view (the next conv's operand), optional raw
 // copy, optional global-average-pool of y (SE / calibration gates, model.py:216,244).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split8(const float (&y)[8], half8& hi, half8& lo, bool& bad) {
+__device__ __forceinline__ void split8(const float (&y)[8], half8& hi, half8& lo, int& bad, float ascale) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float xs = y[j] * ASCALE;
-        bad |= !(fabsf(xs) <= F16_LIMIT);
+        float xs = y[j] * ascale;
+        if (!(fabsf(xs) <= F16_LIMIT)) bad |= (fabsf(y[j]) <= 3.0e38f) ? RANGE_OVERFLOW : RANGE_NONFINITE;
         _Float16 h = (_Float16)xs;
         hi[j] = h;
         lo[j] = (_Float16)(xs - (float)h);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, 
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                    int relu, const float* __restrict__ scale, SplitView out,
                                                    float* __restrict__ out_raw, float* __restrict__ ws,
-                                                   int* __restrict__ errflag) {
+                                                   SplitEnc enc) {
     extern __shared__ float sh[];   // [256][8] for the gap reduction
     // A block covers a slab of at most 64 channels (blockIdx.z): with all C channels per block a wave's stores
     // scatter over C/16 chunk planes in 32-B pieces (2.6 TB/s at C = 512 vs 5.3 TB/s at C = 64 measured).
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, 
         sc[j] = scale ? scale[ci] : 1.f;
         acc[j] = 0.f;
     }
-    bool bad = false;
+    int bad = 0;
     const float* xb = x + (int64_t)b * V * C + g * 8;
     _Float16* ob = out.p ? out.p + (((int64_t)b * out.chunks_total + out.chunk_off + (g >> 1)) * V) * 32 + (g & 1) * 8 : nullptr;
     for (int v = v0 + sub; v < v1; v += SUB) {
@@ -227,12 +227,12 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, 
         }
         if (ob) {
             half8 hi, lo;
-            split8(y, hi, lo, bad);
+            split8(y, hi, lo, bad, enc.ascale);
             *reinterpret_cast<half8*>(ob + (int64_t)v * 32) = hi;
             *reinterpret_cast<half8*>(ob + (int64_t)v * 32 + 16) = lo;
         }
     }
-    if (bad) atomicOr(errflag, 1);
+    if (bad) atomicOr(enc.err, bad);
     if (ws) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) sh[tid * 8 + j] = acc[j];
@@ -252,12 +252,12 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, 
 }
 
 void launch_prep(const float* x, int B, int V, int C, const float* mean, const float* rstd, int relu,
-                 const float* scale, SplitView out, float* out_raw, float* gap, float* ws, int* errflag,
+                 const float* scale, SplitView out, float* out_raw, float* gap, float* ws, SplitEnc enc,
                  hipStream_t st) {
     int Cs = C < 64 ? C : 64, G = Cs / 8, SUB = 256 / G;
     int nblk = pick_blocks(V, SUB * 4, gap ? RED_BLOCKS : 4096);
     hipLaunchKernelGGL(prep_kernel, dim3(nblk, B, C / Cs), dim3(256), 256 * 8 * sizeof(float), st, x, V, C, mean, rstd, relu,
-                       scale, out, out_raw, gap ? ws : nullptr, errflag);
+                       scale, out, out_raw, gap ? ws : nullptr, enc);
     if (gap) launch_finalize_sum(ws, B, nblk, C, 1.0f / (float)V, gap, st);
 }
 
@@ -274,7 +274,7 @@ void launch_prep(const float* x, int B, int V, int C, const float* mean, const f
 __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict__ x, Dims d, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         int relu, const float* __restrict__ scale, SplitView wino,
-                                                        SplitView plain, float* __restrict__ ws, int* __restrict__ errflag) {
+                                                        SplitView plain, float* __restrict__ ws, SplitEnc enc) {
     extern __shared__ float sh[];
     const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
     const int Cs = C < 64 ? C : 64;                 // channel slab per block (see prep_kernel)
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict_
         sc[j] = scale ? scale[ci] : 1.f;
         acc[j] = 0.f;
     }
-    bool bad = false;
+    int bad = 0;
     const float* xb = x + (int64_t)b * V * C + g * 8;
     _Float16* wb = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + (g >> 1)) * 4 * Vh) * 32;
     const int kh = g & 1;                           // which 8 of the chunk's 16 channels: plane q = kh (hi), 2 + kh (lo)
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict_
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             half8 hi, lo;
-            split8(t[pp], hi, lo, bad);
+            split8(t[pp], hi, lo, bad, enc.ascale);
             *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + kh) * Vh + ph) * 8) = hi;
             *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 2 + kh) * Vh + ph) * 8) = lo;
         }
@@ -338,14 +338,14 @@ __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict_
             for (int k = 1; k <= 2; ++k)
                 if (xo - 1 + k < d.W) {
                     half8 hi, lo;
-                    split8(dv[k], hi, lo, bad);
+                    split8(dv[k], hi, lo, bad, enc.ascale);
                     _Float16* o = pb + ((int64_t)row * d.W + xo - 1 + k) * 32;
                     *reinterpret_cast<half8*>(o) = hi;
                     *reinterpret_cast<half8*>(o + 16) = lo;
                 }
         }
     }
-    if (bad) atomicOr(errflag, 1);
+    if (bad) atomicOr(enc.err, bad);
     if (ws) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) sh[tid * 8 + j] = acc[j];
@@ -365,25 +365,25 @@ __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict_
 }
 
 void launch_prep_wino(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, int relu, const float* scale,
-                      SplitView wino, SplitView plain, float* gap, float* ws, int* errflag, hipStream_t st) {
+                      SplitView wino, SplitView plain, float* gap, float* ws, SplitEnc enc, hipStream_t st) {
     int Cs = C < 64 ? C : 64, G = Cs / 8, SUB = 256 / G;
     int Vh = d.D * d.H * ((d.W + 1) / 2);
     int nblk = pick_blocks(Vh, SUB * 2, gap ? RED_BLOCKS : 4096);
     hipLaunchKernelGGL(prep_wino_kernel, dim3(nblk, B, C / Cs), dim3(256), 256 * 8 * sizeof(float), st, x, d, C, mean, rstd, relu, scale,
-                       wino, plain, gap ? ws : nullptr, errflag);
+                       wino, plain, gap ? ws : nullptr, enc);
     if (gap) launch_finalize_sum(ws, B, nblk, C, 1.0f / (float)(d.D * d.H * d.W), gap, st);
 }
 
 // NCDHW f32 [B][C][V] -> wino layout (AF3 encodings for feat_conv, head logits as extra channels)
 __global__ __launch_bounds__(256) void prep_ncdhw_wino_kernel(const float* __restrict__ x, Dims d, int C, SplitView wino,
-                                                              int* __restrict__ errflag) {
+                                                              SplitEnc enc) {
     const int b = blockIdx.z, ch = blockIdx.y;
     const int Wh = (d.W + 1) >> 1;
     const int V = d.D * d.H * d.W, Vh = d.D * d.H * Wh;
     const int ph = blockIdx.x * 256 + threadIdx.x;
     if (ph >= Vh) return;
     const int row = ph / Wh, i = ph - row * Wh, xo = 2 * i;
-    bool bad = false;
+    int bad = 0;
     float t[4][16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -403,28 +403,28 @@ __global__ __launch_bounds__(256) void prep_ncdhw_wino_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) { y0[j] = t[pp][j]; y1[j] = t[pp][8 + j]; }
         half8 hi, lo;
-        split8(y0, hi, lo, bad);
+        split8(y0, hi, lo, bad, enc.ascale);
         *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 0) * Vh + ph) * 8) = hi;
         *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 2) * Vh + ph) * 8) = lo;
-        split8(y1, hi, lo, bad);
+        split8(y1, hi, lo, bad, enc.ascale);
         *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 1) * Vh + ph) * 8) = hi;
         *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 3) * Vh + ph) * 8) = lo;
     }
-    if (bad) atomicOr(errflag, 1);
+    if (bad) atomicOr(enc.err, bad);
 }
-void launch_prep_ncdhw_wino(const float* x, int B, Dims d, int C, SplitView wino, int* errflag, hipStream_t st) {
+void launch_prep_ncdhw_wino(const float* x, int B, Dims d, int C, SplitView wino, SplitEnc enc, hipStream_t st) {
     int Vh = d.D * d.H * ((d.W + 1) / 2);
     dim3 grid((Vh + 255) / 256, (C + 15) / 16, B);
-    hipLaunchKernelGGL(prep_ncdhw_wino_kernel, grid, dim3(256), 0, st, x, d, C, wino, errflag);
+    hipLaunchKernelGGL(prep_ncdhw_wino_kernel, grid, dim3(256), 0, st, x, d, C, wino, enc);
 }
 
 // NCDHW f32 [B][C][V] (the caller's layout, model.py:331) -> split, channels zero-padded to 16.
 __global__ __launch_bounds__(256) void prep_ncdhw_kernel(const float* __restrict__ x, int V, int C, SplitView out,
-                                                         float* __restrict__ abs_sum, int* __restrict__ errflag) {
+                                                         float* __restrict__ abs_sum, SplitEnc enc) {
     const int b = blockIdx.z, ch = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
     float asum = 0.f;
-    bool bad = false;
+    int bad = 0;
     if (v < V) {
         float y[16];
 #pragma unroll
@@ -439,15 +439,15 @@ __global__ __launch_bounds__(256) void prep_ncdhw_kernel(const float* __restrict
             float y0[8], y1[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { y0[j] = y[j]; y1[j] = y[8 + j]; }
-            split8(y0, hi, lo, bad);
+            split8(y0, hi, lo, bad, enc.ascale);
             *reinterpret_cast<half8*>(o) = hi;
             *reinterpret_cast<half8*>(o + 16) = lo;
-            split8(y1, hi, lo, bad);
+            split8(y1, hi, lo, bad, enc.ascale);
             *reinterpret_cast<half8*>(o + 8) = hi;
             *reinterpret_cast<half8*>(o + 24) = lo;
         }
     }
-    if (bad) atomicOr(errflag, 1);
+    if (bad) atomicOr(enc.err, bad);
     if (abs_sum) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) asum += __shfl_xor(asum, o);
@@ -455,9 +455,9 @@ __global__ __launch_bounds__(256) void prep_ncdhw_kernel(const float* __restrict
     }
 }
 
-void launch_prep_ncdhw(const float* x, int B, int V, int C, SplitView out, float* abs_sum, int* errflag, hipStream_t st) {
+void launch_prep_ncdhw(const float* x, int B, int V, int C, SplitView out, float* abs_sum, SplitEnc enc, hipStream_t st) {
     dim3 grid((V + 255) / 256, (C + 15) / 16, B);
-    hipLaunchKernelGGL(prep_ncdhw_kernel, grid, dim3(256), 0, st, x, V, C, out, abs_sum, errflag);
+    hipLaunchKernelGGL(prep_ncdhw_kernel, grid, dim3(256), 0, st, x, V, C, out, abs_sum, enc);
 }
 
 // layout transposes for the op-level entry points (tests): tiled through LDS
@@ -528,7 +528,7 @@ void launch_gate_mlp(const float* pool, const float* premul, int B, int C, int C
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void feat_gate_kernel(const float* __restrict__ x, int V, const float* __restrict__ w0,
                                                         const float* __restrict__ b0, const float* __restrict__ w2,
-                                                        const float* __restrict__ b2, SplitView out, int* __restrict__ errflag) {
+                                                        const float* __restrict__ b2, SplitView out, SplitEnc enc) {
     __shared__ float sw0[16 * 64];
     __shared__ float sb0[16], sw2[16];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void feat_gate_kernel(const float* __restrict_
         z = fmaf(sw2[h], fmaxf(s, 0.f), z);
     }
     const float gt = 1.f / (1.f + expf(-z));
-    bool bad = false;
+    int bad = 0;
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
         _Float16* o = out.p + (((int64_t)b * out.chunks_total + out.chunk_off + ch) * V + v) * 32;
@@ -563,16 +563,16 @@ __global__ __launch_bounds__(256) void feat_gate_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = xv[ch * 16 + kh * 8 + j] * gt;
             half8 hi, lo;
-            split8(y, hi, lo, bad);
+            split8(y, hi, lo, bad, enc.ascale);
             *reinterpret_cast<half8*>(o + kh * 8) = hi;
             *reinterpret_cast<half8*>(o + 16 + kh * 8) = lo;
         }
     }
-    if (bad) atomicOr(errflag, 1);
+    if (bad) atomicOr(enc.err, bad);
 }
 void launch_feat_gate(const float* x, int B, int V, const float* w0, const float* b0, const float* w2, const float* b2,
-                      SplitView out, int* errflag, hipStream_t st) {
-    hipLaunchKernelGGL(feat_gate_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, x, V, w0, b0, w2, b2, out, errflag);
+                      SplitView out, SplitEnc enc, hipStream_t st) {
+    hipLaunchKernelGGL(feat_gate_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, x, V, w0, b0, w2, b2, out, enc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -583,7 +583,7 @@ void launch_feat_gate(const float* x, int B, int V, const float* w0, const float
 __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict__ x, int V, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ gate,
                                                          const float* __restrict__ wf, const float* __restrict__ bf, int ncls,
-                                                         float* __restrict__ logits, SplitView extra, int extra_off,
+                                                         float* __restrict__ logits, int extra_off,
                                                          float* __restrict__ extra_raw, int extra_raw_c) {
     __shared__ float sw[21 * 32];
     __shared__ float sm[32], sr[32], sg[32], sb[21];
@@ -603,26 +603,19 @@ __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) t[j] = fmaxf((t[j] - sm[j]) * sr[j], 0.f) * sg[j];
-    _Float16* eo = extra.p ? extra.p + (((int64_t)b * extra.chunks_total + extra.chunk_off) * V + v) * 32 : nullptr;
     for (int n = 0; n < ncls; ++n) {
         float s = sb[n];
 #pragma unroll
         for (int j = 0; j < 32; ++j) s = fmaf(sw[n * 32 + j], t[j], s);
         logits[((int64_t)b * ncls + n) * V + v] = s;
         if (extra_raw) extra_raw[((int64_t)b * extra_raw_c + extra_off + n) * V + v] = s;
-        if (eo) {
-            float xs = s * ASCALE;
-            _Float16 h = (_Float16)xs;
-            eo[extra_off + n] = h;
-            eo[16 + extra_off + n] = (_Float16)(xs - (float)h);
-        }
     }
 }
 void launch_head_final(const float* x, int B, int V, const float* mean, const float* rstd, const float* gate,
-                       const float* wf, const float* bf, int ncls, float* logits, SplitView extra, int extra_ch_off,
-                       float* extra_raw, int extra_raw_c, hipStream_t st) {
+                       const float* wf, const float* bf, int ncls, float* logits, int extra_ch_off, float* extra_raw,
+                       int extra_raw_c, hipStream_t st) {
     hipLaunchKernelGGL(head_final_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, x, V, mean, rstd, gate, wf, bf,
-                       ncls, logits, extra, extra_ch_off, extra_raw, extra_raw_c);
+                       ncls, logits, extra_ch_off, extra_raw, extra_raw_c);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -271,6 +271,15 @@ class Engine:
         self._check(self.lib.mica_op_stem(self._h, _ptr(m), B, d, h, w, _ptr(y), self._stream()), "mica_op_stem")
         return y
 
+    @property
+    def activation_scale(self) -> float:
+        """Scale of the split-f16 operand encoding: 16 unless an activation overflowed and the library stepped it down."""
+        return float(self.lib.mica_get_activation_scale(self._h))
+
+    @activation_scale.setter
+    def activation_scale(self, v: float):
+        self._check(self.lib.mica_set_activation_scale(self._h, float(v)), "mica_set_activation_scale")
+
     def set_profiling(self, on: bool):
         self._check(self.lib.mica_set_profiling(self._h, int(on)), "mica_set_profiling")
 
