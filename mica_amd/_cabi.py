@@ -29,6 +29,7 @@ SIGNATURES = {
     "mica_finalize_weights": (_I, [_P]),
     "mica_forward_logits": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "mica_forward_tiles": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "mica_forward_records": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "mica_postprocess": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "mica_tile_count": (_L, [_L, _L, _L, _I]),
     "mica_tile_table": (_L, [_L, _L, _L, _I, _LP, _L]),
@@ -40,7 +41,11 @@ SIGNATURES = {
     "mica_threshold_points": (_I, [_P, _P, _L, _F, _P, _L, _LP, _P]),
     "mica_gather_values": (_I, [_P, _P, _I, _L, _P, _L, _P, _P]),
     "mica_refine_candidates": (_I, [_P, _P, _P, _L, _L, _L, _P, _L, _P, _P, _P, _P]),
+    "mica_segment_sums": (_I, [_P, _P, _P, _L, _P, _P]),
+    "mica_nms_points": (_I, [_P, _P, _L, _L, _L, _L, C.c_double, _P, _P]),
+    "mica_neighbour_matrix": (_I, [_P, _P, _L, _P, _L, _L, _L, _P, _P, _P]),
     "mica_op_conv3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _I, _P, _P]),
+    "mica_op_norm_conv1_conv3": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _FP, _FP, _I, _P, _P]),
     "mica_op_instnorm_relu": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mica_op_depthwise3": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _P, _P]),
     "mica_op_stem": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),

@@ -12,7 +12,7 @@ namespace mica {
 //         then 16 "lo" halves with  x * ascale = hi + lo (+ ~2^-22 relative).  This is what the
 //         MFMA conv consumes: three f16 MFMAs (hi*hi, hi*lo, lo*hi) give ~fp32 products.
 // `ascale` is a power of two carried by the context: 16 by default (keeps `lo` out of f16 subnormals for |x| >= 2^-7);
-// when an activation overflows the f16 range at that scale (|x| > 3750) the forward is repeated with ascale / 16
+// when an activation overflows the f16 range at that scale (|x| > 3750) the forward is repeated with ascale / 4
 // (forward.hip: forward_checked), down to 2^-8 (|x| < 1.5e7).  Scaling by a power of two is exact, and the conv epilogues
 // undo it (out_scale = 1 / (wscale * ascale)).
 constexpr float ASCALE_DEFAULT = 16.0f;
@@ -46,12 +46,27 @@ struct ConvSrcs {
 
 struct Dims { int D, H, W; };  // one tile
 
+// Sources of a 1x1x1 conv (kernels_conv1x1.hip): the virtual channel concatenation of up to two tensors, each either an
+// operand in split form or the RAW f32 output of its producer with the InstanceNorm constants to apply on load.
+struct Conv1Src {
+    const void* p;          // split: _Float16 [B][chunks_total][V][2][16] ; raw: float [B][V][16 * chunks_total]
+    const float* mean;      // raw only, nullable (identity): per (b, channel) of the raw tensor
+    const float* rstd;
+    int kind;               // 0 split, 1 raw
+    int chunks;             // 16-channel chunks this source contributes
+    int chunks_total;       // chunks per batch entry of the buffer (raw: channels / 16)
+    int chunk_off;          // first chunk within the buffer
+    int relu;               // raw: ReLU after the normalisation
+};
+struct Conv1Srcs { Conv1Src s[2]; int n; };
+
 // ---- launchers (kernels_*.hip) -----------------------------------------------------------------
-// Dense conv (k=1 or 3) on split inputs.  wpk: packed weights [B?][chunks][taps][4][Cout][8] halves,
-// wpk_bstride = halves between batch entries (0 = shared).  out raw f32 [B][V][Cout]:
-// out = acc * out_scale + bias.
-void launch_conv_mfma(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
-                      float out_scale, float* out, int B, Dims d, int cout, int ksize, hipStream_t st);
+// 1x1x1 conv, cout in {64, 128, 256}: out = acc * out_scale + bias written either as raw f32 [B][V][cout] (out_raw) or straight
+// as the Winograd operand of the 3^3 conv that follows (wino; needs conv1x1_can_emit_wino(d): whole x rows per workgroup).
+// wpk as launch_pack_weights(ksize = 1) lays it out.
+void launch_conv1x1(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out_raw,
+                    SplitView wino, int B, Dims d, int cout, SplitEnc enc, hipStream_t st);
+bool conv1x1_can_emit_wino(Dims d);
 // Pack torch-layout conv weights into wpk.  seg_c/seg_cp: per-source real and padded channel counts.
 // cin_scale f32[B][Cin] (nullable) multiplies input channels (gate folding); cout_scale scalar.
 void launch_pack_weights(const float* w, int cout, int cin, int ksize, const int* h_seg_c, const int* h_seg_cp,
@@ -83,10 +98,14 @@ void launch_fill_float(float* p, int64_t n, float v, hipStream_t st);
 
 // depthwise 3^3 on raw input with fused (x-mean)*rstd, relu, *scale applied on load (zero padding after)
 // C must be a multiple of 16.  stats_ws (nullable): fused InstanceNorm partials, returns their count P.
+// gap_ws (nullable): f32 [B][P][C] per-block sums of the normalised input over the block's own voxels (launch_finalize_sum).
 int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
-                     const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, hipStream_t st);
-// merge P partials f32 [B][P][C][3] = (count, mean, M2) into mean / rstd
-void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, float* mean, float* rstd, hipStream_t st);
+                     const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st);
+// merge P partials f32 [B][P][C][3] = (count, mean, M2) into mean / rstd.  gate f32 [B][C] (nullable): the statistics are
+// those of u while the tensor that is normalised downstream is t = g u + const (g > 0 per tile and channel): then
+// (t - mean_t) / sqrt(var_t + eps) = (u - mean_u) * g / sqrt(g^2 var_u + eps), i.e. rstd = g / sqrt(g^2 var_u + eps).
+void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, float* mean, float* rstd, hipStream_t st,
+                           const float* gate = nullptr);
 int64_t fused_stats_ws_floats(int B, int tile_size);
 // stem: map f32 [B][V] -> split view of 128 channels + gap[b][128] (mean over voxels)
 void launch_stem(const float* map, int B, Dims d, const float* wstem, const float* bstem, SplitView out,
@@ -112,7 +131,7 @@ void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_se
                               hipStream_t st);
 int64_t packed_weight_halves_wino(int cout, int total_chunks);
 void launch_postprocess(const float* bb, const float* ca, const float* aa, int B, int V, float* bbp, float* cap,
-                        float* aap, float* aapred, hipStream_t st);
+                        float* aap, float* aapred, int64_t s1, int64_t s20, hipStream_t st);
 
 void launch_gather_tiles(const float* vol, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
                          int64_t first, int64_t count, float* tiles, hipStream_t st);
@@ -135,5 +154,11 @@ int gather_values_device(const float* d_vol, int C, int64_t nvox, const int64_t*
                          int errlen);
 int refine_candidates_device(const float* d_ca, const float* d_aa, int n0, int n1, int n2, const int* d_cand, int64_t n, double* d_coord,
                              float* d_aa_out, int* d_ok, hipStream_t st, char* err, int errlen);
+
+// modeler.py:776-787 (np.sum per cluster, numpy's summation order), :822-831 (greedy NMS over sorted candidates), :860-888
+int segment_sums_device(const float* d_vals, const int64_t* d_seg_off, int64_t nseg, float* d_sums, hipStream_t st, char* err, int errlen);
+int nms_points_device(const int* d_pts, int64_t n, int n0, int n1, int n2, double radius, int* d_keep, hipStream_t st, char* err, int errlen);
+int neighbour_matrix_device(const double* d_cands, int64_t n, const float* d_bb, int n0, int n1, int n2, double* d_dis, double* d_mat,
+                            hipStream_t st, char* err, int errlen);
 
 }  // namespace mica

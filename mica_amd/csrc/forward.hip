@@ -82,12 +82,13 @@ struct mica_ctx {
     Head heads[3];
 
     // activations
-    // operands of 3^3 convs are in wino layout (2x bytes), those of 1x1 convs plain split; S_cp = plain copies for the 1x1 laterals
-    _Float16 *S_exp, *S_af, *S_fw, *S_x0, *S_1, *S_2, *S_3, *S_dw, *S_f, *S_c[3], *S_cp[3], *S_l, *S_fpn, *S_extra, *S_h1;
+    // operands of 3^3 convs are in wino layout (2x bytes); the 1x1 convs read plain split operands (S_exp, S_fw) or raw f32 tensors
+    _Float16 *S_exp, *S_af, *S_fw, *S_x0, *S_1, *S_2, *S_f, *S_c[3], *S_l, *S_fpn, *S_extra, *S_h1;
     float* extra_raw = nullptr;   // [B][8][V] backbone + CA logits (NCDHW) feeding the next heads' conv1
     float *R_a, *R_b, *R_c;
     float *logits[3];             // internal NCDHW logits when the caller wants probabilities only
     float* ws = nullptr;          // reduction partials
+    float* ws_gap = nullptr;      // depthwise: per-block sums of its normalised input [B][blocks][C]
     float *v_mean, *v_rstd, *v_mean3, *v_rstd3, *v_pool, *v_gse, *v_gate, *v_abs;
     int* d_err = nullptr;
     float ascale = ASCALE_DEFAULT;   // activation scale of the split encoding (common.h); lowered by forward_checked on overflow
@@ -249,27 +250,42 @@ void prof_end(mica_ctx* c, int kind, double work, hipStream_t st) {
     c->prof_work[kind] += work;
 }
 
-// Launch a dense conv.  With `norm` (mean/rstd destination given) the InstanceNorm statistics of the output are
-// produced too: fused into the Winograd kernel's epilogue, or by the separate streaming pass otherwise.
+// Launch a dense 3x3x3 conv (Winograd kernel).  With `mean`/`rstd` given the InstanceNorm statistics of the output are
+// produced too (fused into the kernel's epilogue, merged by stats_finalize).
 void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, hipStream_t st, float* mean = nullptr,
               float* rstd = nullptr) {
+    prof_begin(c, 2, st);
+    const int P = launch_conv_wino(src.s, L.d_wpk, 0, L.d_b, 1.0f / (L.wscale * c->ascale), out, B, c->d, L.cout, mean ? c->ws : nullptr, st);
+    prof_end(c, 2, L.flops_per_voxel * (double)c->V * B, st);
+    if (mean) launch_stats_finalize(c->ws, B, P, L.cout, 1e-5f, mean, rstd, st);
+}
+
+Conv1Src split_src(const _Float16* p, int chunks_total, int off, int chunks) {
+    return Conv1Src{p, nullptr, nullptr, 0, chunks, chunks_total, off, 0};
+}
+Conv1Src raw_src(const float* p, int channels, const float* mean, const float* rstd, int relu) {
+    return Conv1Src{p, mean, rstd, 1, channels / 16, channels / 16, 0, relu};
+}
+
+void make_operand(mica_ctx* c, const float* raw, int B, int C, const float* mean, const float* rstd, int relu, SplitView t3, SplitView t1,
+                  float* gap, hipStream_t st);
+
+// A 1x1x1 conv whose output is the Winograd operand `dst` of the 3^3 conv that follows.  The kernel writes the operand itself
+// when a workgroup owns whole x rows; otherwise it writes raw f32 to `tmp_raw` and the operand pass follows.
+void run_conv1x1(mica_ctx* c, ConvLayer& L, Conv1Src a, const Conv1Src* b2, SplitView dst, float* tmp_raw, int B, hipStream_t st) {
     if (L.per_tile)
-        launch_pack_weights(L.d_w, L.cout, L.cin, L.k, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(),
-                            L.d_cin_scale, B, L.cout_scale, L.wscale, L.d_wpk, st);
-    const int pk = L.k == 3 ? 2 : 4;
-    prof_begin(c, pk, st);
-    int P = 0;
-    if (L.wino)
-        P = launch_conv_wino(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * c->ascale), out, B, c->d, L.cout,
-                             mean ? c->ws : nullptr, st);
-    else
-        launch_conv_mfma(src.s, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * c->ascale), out, B, c->d, L.cout,
-                         L.k, st);
-    prof_end(c, pk, L.flops_per_voxel * (double)c->V * B, st);
-    if (mean) {
-        if (L.wino) launch_stats_finalize(c->ws, B, P, L.cout, 1e-5f, mean, rstd, st);
-        else launch_stats(out, B, c->V, L.cout, 1e-5f, mean, rstd, c->ws, st);
-    }
+        launch_pack_weights(L.d_w, L.cout, L.cin, 1, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(), L.d_cin_scale, B, L.cout_scale,
+                            L.wscale, L.d_wpk, st);
+    Conv1Srcs src{};
+    src.n = b2 ? 2 : 1;
+    src.s[0] = a;
+    if (b2) src.s[1] = *b2;
+    const bool fused = conv1x1_can_emit_wino(c->d);
+    prof_begin(c, 4, st);
+    launch_conv1x1(src, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * c->ascale), fused ? nullptr : tmp_raw,
+                   fused ? dst : SplitView{nullptr, 0, 0, 0}, B, c->d, L.cout, SplitEnc{c->d_err, c->ascale}, st);
+    prof_end(c, 4, L.flops_per_voxel * (double)c->V * B, st);
+    if (!fused) make_operand(c, tmp_raw, B, L.cout, nullptr, nullptr, 0, dst, SplitView{nullptr, 0, 0, 0}, nullptr, st);
 }
 
 void gate(mica_ctx* c, const GateMLP& g, const float* pool, const float* premul, int B, const float* postmul, float* out,
@@ -302,15 +318,15 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
     launch_stem(d_map, B, d, c->stem_w, c->stem_b, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, c->ws, c->ascale, st);
     if (!use_af) {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->downsizing.d_cin_scale, 128, st);
-        run_conv(c, c->downsizing, SrcList().add(c->S_exp, 8, 0, 8), c->R_a, B, st);
+        run_conv1x1(c, c->downsizing, split_src(c->S_exp, 8, 0, 8), nullptr, view(c->S_x0, 4, 0, 4), c->R_a, B, st);
     } else {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->fusion0.d_cin_scale, 192, st);
         launch_prep_ncdhw_wino(d_af, B, d, 24, view(c->S_af, 2, 0, 2), SplitEnc{c->d_err, c->ascale}, st);
         run_conv(c, c->feat_conv, SrcList().add(c->S_af, 2, 0, 2), c->R_b, B, st);
         launch_feat_gate(c->R_b, B, V, c->fg_w0, c->fg_b0, c->fg_w2, c->fg_b2, view(c->S_fw, 4, 0, 4), SplitEnc{c->d_err, c->ascale}, st);
-        run_conv(c, c->fusion0, SrcList().add(c->S_exp, 8, 0, 8).add(c->S_fw, 4, 0, 4), c->R_a, B, st);
+        const Conv1Src fw = split_src(c->S_fw, 4, 0, 4);
+        run_conv1x1(c, c->fusion0, split_src(c->S_exp, 8, 0, 8), &fw, view(c->S_x0, 4, 0, 4), c->R_a, B, st);
     }
-    make_operand(c, c->R_a, B, 64, nullptr, nullptr, 0, view(c->S_x0, 4, 0, 4), none, nullptr, st);
 
     // ---- encoders (model.py:149-152) -----------------------------------------------------------
     const _Float16* X = c->S_x0;
@@ -324,34 +340,36 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_2, ch, 0, ch), none, nullptr, st);
         run_conv(c, E.conv3, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch).add(c->S_2, ch, 0, ch), c->R_b, B, st, c->v_mean3,
                  c->v_rstd3);
-        make_operand(c, c->R_b, B, C, c->v_mean3, c->v_rstd3, 1, none, view(c->S_3, cc, 0, cc), c->v_pool, st);
-        // SEBlock gate (model.py:254-258); applied downstream: folded into the depthwise load and the fusion weights
-        gate(c, E.se, c->v_pool, nullptr, B, nullptr, c->v_gse, nullptr, 0, st);
+        // x3 = relu(IN(conv3)) is never materialised: the depthwise conv and the 1x1 fusion normalise the raw tensor on load,
+        // and its global average pool (the SE gate's input, model.py:256) is summed by the depthwise kernel as it loads.
+        // The SE gate g (per tile and channel, > 0) scales the depthwise conv's INPUT (model.py:258, 99); the conv is linear, so
+        // it runs on the ungated tensor (R_c = w * x3 + b) and the gate moves into the InstanceNorm constants of its output:
+        // IN(g (R_c - b) + b) = (R_c - mean) g / sqrt(g^2 var + eps).
         // DualAttention (model.py:98-101): local branch
         {
             prof_begin(c, 1, st);
-            const int P = launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, c->v_gse, E.dw_w, E.dw_b, c->R_c, c->ws, st);
+            const int P = launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, nullptr, E.dw_w, E.dw_b, c->R_c, c->ws, c->ws_gap, st);
             prof_end(c, 1, 8.0 * (double)C * V * B, st);     // algorithmic bytes: read + write 4 B per voxel and channel
-            launch_stats_finalize(c->ws, B, P, C, 1e-5f, c->v_mean, c->v_rstd, st);
+            launch_finalize_sum(c->ws_gap, B, P, C, 1.0f / (float)V, c->v_pool, st);
+            gate(c, E.se, c->v_pool, nullptr, B, nullptr, c->v_gse, nullptr, 0, st);      // SEBlock gate (model.py:254-258)
+            launch_stats_finalize(c->ws, B, P, C, 1e-5f, c->v_mean, c->v_rstd, st, c->v_gse);
         }
-        make_operand(c, c->R_c, B, C, c->v_mean, c->v_rstd, 1, none, view(c->S_dw, cc, 0, cc), nullptr, st);
         // global branch: GAP(se(x3)) = g_se * GAP(x3); global_feat = g_ga * g_se * x3 folded into fusion's weights
         gate(c, E.ga, c->v_pool, c->v_gse, B, c->v_gse, nullptr, E.fusion.d_cin_scale + C, 2 * C, st);
-        run_conv(c, E.fusion, SrcList().add(c->S_dw, cc, 0, cc).add(c->S_3, cc, 0, cc), c->R_a, B, st);
-        make_operand(c, c->R_a, B, C, nullptr, nullptr, 0, view(c->S_f, cc, 0, cc), none, nullptr, st);
+        {
+            // fusion (model.py:96, 101) reads the two branches raw: local = relu(IN(depthwise)), global = relu(IN(conv3)) * gates
+            const Conv1Src glob = raw_src(c->R_b, C, c->v_mean3, c->v_rstd3, 1);
+            run_conv1x1(c, E.fusion, raw_src(c->R_c, C, c->v_mean, c->v_rstd, 1), &glob, view(c->S_f, cc, 0, cc), c->R_a, B, st);
+        }
         // transition (model.py:141-147); c_e feeds the next encoder's 3^3 convs and the FPN's 1x1 lateral
         run_conv(c, E.transition, SrcList().add(c->S_f, cc, 0, cc), c->R_a, B, st, c->v_mean, c->v_rstd);
-        make_operand(c, c->R_a, B, 2 * C, c->v_mean, c->v_rstd, 1, e < 2 ? view(c->S_c[e], 2 * cc, 0, 2 * cc) : none,
-                     view(c->S_cp[e], 2 * cc, 0, 2 * cc), nullptr, st);
+        if (e < 2) make_operand(c, c->R_a, B, 2 * C, c->v_mean, c->v_rstd, 1, view(c->S_c[e], 2 * cc, 0, 2 * cc), none, nullptr, st);
+        // FPN level e right away (model.py:182-205; the interpolations are identities): the lateral 1x1 reads c_e raw with the
+        // transition's InstanceNorm + ReLU applied on load, and writes the smoothing conv's operand
+        run_conv1x1(c, c->lateral[e], raw_src(c->R_a, 2 * C, c->v_mean, c->v_rstd, 1), nullptr, view(c->S_l, 4, 0, 4), c->R_c, B, st);
+        run_conv(c, c->smooth[e], SrcList().add(c->S_l, 4, 0, 4), c->R_b, B, st);
+        make_operand(c, c->R_b, B, 64, nullptr, nullptr, 0, view(c->S_fpn, 12, 4 * e, 4), none, nullptr, st);
         X = c->S_c[e];
-    }
-    // ---- FPN (model.py:182-205; the interpolations are identities) ------------------------------
-    for (int i = 0; i < 3; ++i) {
-        const int cc = (128 << i) / 16;
-        run_conv(c, c->lateral[i], SrcList().add(c->S_cp[i], cc, 0, cc), c->R_a, B, st);
-        make_operand(c, c->R_a, B, 64, nullptr, nullptr, 0, view(c->S_l, 4, 0, 4), none, nullptr, st);
-        run_conv(c, c->smooth[i], SrcList().add(c->S_l, 4, 0, 4), c->R_b, B, st);
-        make_operand(c, c->R_b, B, 64, nullptr, nullptr, 0, view(c->S_fpn, 12, 4 * i, 4), none, nullptr, st);
     }
     // ---- heads (model.py:230-239, 344-346) ------------------------------------------------------
     hipMemsetAsync(c->extra_raw, 0, sizeof(float) * (size_t)B * 8 * V, st);
@@ -443,8 +461,9 @@ bool pow2_8_512(int c) { return c >= 8 && c <= 512 && (c & (c - 1)) == 0; }
 
 
 // The forward with the range check of the split-f16 encoding (synchronises `st`).  An activation beyond the f16 range at
-// the current activation scale (|x| * ascale > 60000) repeats the forward at ascale / 16 - exact, the epilogues undo the
-// power of two - and the lower scale stays with the context; NaN/Inf, or an overflow at the smallest scale, fail loudly
+// the current activation scale (|x| * ascale > 60000) repeats the forward at ascale / 4 - exact, the epilogues undo the
+// power of two - and the lower scale stays with the context (small steps: below ~1 the lo halves of O(1) activations go
+// subnormal in f16 and the whole-network error grows, 5.6e-5 at scale 1 -> 1.2e-4 at 1/16 on the synthetic weights); NaN/Inf, or an overflow at the smallest scale, fail loudly
 // with MICA_ERR_RANGE rather than return clipped numbers.
 static int forward_checked(mica_ctx* c, const float* d_map, const float* d_af, int B, int af_mode, float* o_bb, float* o_ca,
                            float* o_aa, hipStream_t st) {
@@ -460,7 +479,7 @@ static int forward_checked(mica_ctx* c, const float* d_map, const float* d_af, i
                                               : "activation outside the representable range of the split-f16 conv path (|x| > 1.5e7)";
             return MICA_ERR_RANGE;
         }
-        c->ascale *= 1.0f / 16.0f;
+        c->ascale *= 0.25f;
     }
 }
 
@@ -504,9 +523,8 @@ int mica_create(int device, int max_batch, int tile_size, mica_ctx** out) {
     auto S = [&](_Float16** p, int ch) { if (!r) r = dalloc(c, p, BV * ch * 2); };                        // plain: hi + lo
     auto W3 = [&](_Float16** p, int ch) { if (!r) r = dalloc(c, p, BVw * ch * 2); };                       // operand of 3^3 convs
     S(&c->S_exp, 128); W3(&c->S_af, 32); S(&c->S_fw, 64); W3(&c->S_x0, 64);
-    W3(&c->S_1, 128); W3(&c->S_2, 128); S(&c->S_3, 256); S(&c->S_dw, 256); W3(&c->S_f, 256);
+    W3(&c->S_1, 128); W3(&c->S_2, 128); W3(&c->S_f, 256);
     W3(&c->S_c[0], 128); W3(&c->S_c[1], 256); c->S_c[2] = nullptr;
-    S(&c->S_cp[0], 128); S(&c->S_cp[1], 256); S(&c->S_cp[2], 512);
     W3(&c->S_l, 64); W3(&c->S_fpn, 192); W3(&c->S_extra, 16); W3(&c->S_h1, 64);
     if (!r) r = dalloc(c, &c->extra_raw, BV * 8);
     auto R = [&](float** p, int ch) { if (!r) r = dalloc(c, p, BV * ch); };
@@ -517,6 +535,7 @@ int mica_create(int device, int max_batch, int tile_size, mica_ctx** out) {
     if (stem_ws > wsn) wsn = stem_ws;
     if (fused_stats_ws_floats(max_batch, tile_size) > wsn) wsn = fused_stats_ws_floats(max_batch, tile_size);
     if (!r) r = dalloc(c, &c->ws, wsn);
+    if (!r) r = dalloc(c, &c->ws_gap, (int64_t)max_batch * ((tile_size + 15) / 16) * ((tile_size + 7) / 8) * 256);
     auto Vv = [&](float** p) { if (!r) r = dalloc(c, p, (int64_t)max_batch * 512); };
     Vv(&c->v_mean); Vv(&c->v_rstd); Vv(&c->v_mean3); Vv(&c->v_rstd3); Vv(&c->v_pool); Vv(&c->v_gse); Vv(&c->v_gate); Vv(&c->v_abs);
     if (!r) r = dalloc(c, &c->d_err, 4);
@@ -666,7 +685,7 @@ int mica_postprocess(mica_ctx* c, const float* d_bb, const float* d_ca, const fl
     if (!c) return MICA_ERR_ARG;
     if (!d_bb || !d_ca || !d_aa || !d_bb_prob || !d_ca_prob || !d_aa_prob || !d_aa_pred || batch < 1) { c->err = "mica_postprocess: bad argument"; return MICA_ERR_ARG; }
     HIPC(c, hipSetDevice(c->device));
-    launch_postprocess(d_bb, d_ca, d_aa, batch, c->V, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, (hipStream_t)stream);
+    launch_postprocess(d_bb, d_ca, d_aa, batch, c->V, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, c->V, (int64_t)20 * c->V, (hipStream_t)stream);
     HIPC(c, hipGetLastError());
     return MICA_OK;
 }
@@ -678,6 +697,18 @@ int mica_forward_tiles(mica_ctx* c, const float* d_map, const float* d_af, int b
     int r = forward_checked(c, d_map, d_af, batch, af_mode, c->logits[0], c->logits[1], c->logits[2], st);
     if (r) return r;
     return mica_postprocess(c, c->logits[0], c->logits[1], c->logits[2], batch, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, stream);
+}
+
+int mica_forward_records(mica_ctx* c, const float* d_map, const float* d_af, int batch, int af_mode, float* d_rec, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_rec) { c->err = "mica_forward_records: null pointer argument"; return MICA_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    int r = forward_checked(c, d_map, d_af, batch, af_mode, c->logits[0], c->logits[1], c->logits[2], st);
+    if (r) return r;
+    const int64_t V = c->V;
+    launch_postprocess(c->logits[0], c->logits[1], c->logits[2], batch, c->V, d_rec, d_rec + V, d_rec + 3 * V, d_rec + 2 * V, 23 * V, 23 * V, st);
+    HIPC(c, hipGetLastError());
+    return MICA_OK;
 }
 
 int64_t mica_tile_count(int64_t n0, int64_t n1, int64_t n2, int grid) {
@@ -819,12 +850,52 @@ int mica_refine_candidates(mica_ctx* c, const float* d_ca, const float* d_aa, in
     return r;
 }
 
+int mica_segment_sums(mica_ctx* c, const float* d_vals, const int64_t* d_seg_off, int64_t nseg, float* d_sums, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (nseg < 0 || (nseg > 0 && (!d_vals || !d_seg_off || !d_sums))) { c->err = "mica_segment_sums: bad argument"; return MICA_ERR_ARG; }
+    HIPC(c, hipSetDevice(c->device));
+    char buf[256] = {0};
+    int r = segment_sums_device(d_vals, d_seg_off, nseg, d_sums, (hipStream_t)stream, buf, sizeof(buf));
+    if (r) c->err = buf;
+    return r;
+}
+
+int mica_nms_points(mica_ctx* c, const int32_t* d_pts, int64_t n, int64_t n0, int64_t n1, int64_t n2, double radius, int32_t* d_keep,
+                    void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (n < 0 || n > 0x7fffffff || n0 < 1 || n1 < 1 || n2 < 1 || n0 > 4096 || n1 > 4096 || n2 > 4096 || !(radius >= 0.0 && radius < 1e6) ||
+        (n > 0 && (!d_pts || !d_keep))) {
+        c->err = "mica_nms_points: bad argument";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    char buf[256] = {0};
+    int r = nms_points_device(d_pts, n, (int)n0, (int)n1, (int)n2, radius, d_keep, (hipStream_t)stream, buf, sizeof(buf));
+    if (r) c->err = buf;
+    return r;
+}
+
+int mica_neighbour_matrix(mica_ctx* c, const double* d_cands, int64_t n, const float* d_bb, int64_t n0, int64_t n1, int64_t n2,
+                          double* d_dis, double* d_mat, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (n < 0 || n > 65535 || n0 < 1 || n1 < 1 || n2 < 1 || n0 > 4096 || n1 > 4096 || n2 > 4096 || (n > 0 && (!d_cands || !d_bb || !d_dis || !d_mat))) {
+        c->err = "mica_neighbour_matrix: bad argument";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    char buf[256] = {0};
+    int r = neighbour_matrix_device(d_cands, n, d_bb, (int)n0, (int)n1, (int)n2, d_dis, d_mat, (hipStream_t)stream, buf, sizeof(buf));
+    if (r) c->err = buf;
+    return r;
+}
+
 // ---- single-op entry points (test harness for the individual kernels) ---------------------------
 int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w, const float* h_b,
                    int cout, int k, float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
-    if (!d_x || !h_w || !h_b || !d_y || batch < 1 || cin < 1 || cout < 32 || cout % 32 || (k != 1 && k != 3) || d < 1 || h < 1 || w < 1) {
-        c->err = "mica_op_conv3d: bad argument (cout must be a multiple of 32, k in {1,3})";
+    if (!d_x || !h_w || !h_b || !d_y || batch < 1 || cin < 1 || cout < 32 || cout % 32 || (k != 1 && k != 3) || d < 1 || h < 1 || w < 1 ||
+        (k == 1 && cout != 64 && cout != 128 && cout != 256)) {
+        c->err = "mica_op_conv3d: bad argument (k = 3: cout a multiple of 32; k = 1: cout in {64, 128, 256})";
         return MICA_ERR_ARG;
     }
     HIPC(c, hipSetDevice(c->device));
@@ -855,8 +926,73 @@ int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int
     } else {
         launch_prep_ncdhw(d_x, batch, V, cin, SplitView{sx, cp / 16, 0, cp / 16}, nullptr, SplitEnc{derr, ASCALE_DEFAULT}, st);
         launch_pack_weights(dw, cout, cin, k, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
-        launch_conv_mfma(s, pk, 0, db, 1.0f / (ws * ASCALE_DEFAULT), raw, batch, Dims{d, h, w}, cout, k, st);
+        Conv1Srcs s1{};
+        s1.n = 1;
+        s1.s[0] = Conv1Src{sx, nullptr, nullptr, 0, cp / 16, cp / 16, 0, 0};
+        launch_conv1x1(s1, pk, 0, db, 1.0f / (ws * ASCALE_DEFAULT), raw, SplitView{nullptr, 0, 0, 0}, batch, Dims{d, h, w}, cout,
+                       SplitEnc{derr, ASCALE_DEFAULT}, st);
     }
+    launch_nhwc_to_nchw(raw, batch, cout, V, d_y, st);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(st));
+    return MICA_OK;
+}
+
+int mica_op_norm_conv1_conv3(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w1, const float* h_b1,
+                             int cmid, const float* h_w3, const float* h_b3, int cout, float* d_y, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_x || !h_w1 || !h_b1 || !h_w3 || !h_b3 || !d_y || batch < 1 || cin < 16 || !pow2_8_512(cin) || (cmid != 64 && cmid != 128 && cmid != 256) ||
+        cout < 32 || cout % 32 || d < 1 || h < 1 || w < 1) {
+        c->err = "mica_op_norm_conv1_conv3: bad argument (cin a power of two in [16,512], cmid in {64,128,256}, cout a multiple of 32)";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const Dims dm{d, h, w};
+    const int V = d * h * w;
+    const int64_t Vw = (int64_t)d * h * ((w + 1) / 2) * 4;
+    Tmp t;
+    float* xr = t.get<float>((int64_t)batch * V * cin);              // raw NDHWC input
+    float* mean = t.get<float>((int64_t)batch * cin);
+    float* rstd = t.get<float>((int64_t)batch * cin);
+    float* ws = t.get<float>(stats_ws_floats(batch, cin));
+    float* mid = t.get<float>((int64_t)batch * V * cmid);            // only when the operand cannot be emitted directly
+    _Float16* op = t.get<_Float16>((int64_t)batch * Vw * cmid * 2);
+    float* raw = t.get<float>((int64_t)batch * V * cout);
+    float* dw1 = t.get<float>((int64_t)cmid * cin);
+    float* db1 = t.get<float>(cmid);
+    float* dw3 = t.get<float>((int64_t)cout * cmid * 27);
+    float* db3 = t.get<float>(cout);
+    _Float16* pk1 = t.get<_Float16>(packed_weight_halves(cmid, 1, cin / 16));
+    _Float16* pk3 = t.get<_Float16>(packed_weight_halves_wino(cout, cmid / 16));
+    int* derr = t.get<int>(1);
+    if (!xr || !mean || !rstd || !ws || !mid || !op || !raw || !dw1 || !db1 || !dw3 || !db3 || !pk1 || !pk3 || !derr) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
+    std::vector<float> v1(h_w1, h_w1 + (size_t)cmid * cin), v3(h_w3, h_w3 + (size_t)cout * cmid * 27);
+    const float s1 = pick_wscale(v1, 1.f), s3 = pick_wscale(v3, 1.f);
+    HIPC(c, hipMemcpyAsync(dw1, h_w1, sizeof(float) * cmid * cin, hipMemcpyHostToDevice, st));
+    HIPC(c, hipMemcpyAsync(db1, h_b1, sizeof(float) * cmid, hipMemcpyHostToDevice, st));
+    HIPC(c, hipMemcpyAsync(dw3, h_w3, sizeof(float) * cout * cmid * 27, hipMemcpyHostToDevice, st));
+    HIPC(c, hipMemcpyAsync(db3, h_b3, sizeof(float) * cout, hipMemcpyHostToDevice, st));
+    HIPC(c, hipMemsetAsync(derr, 0, 4, st));
+    const SplitEnc enc{derr, ASCALE_DEFAULT};
+    launch_nchw_to_nhwc(d_x, batch, cin, V, xr, st);
+    launch_stats(xr, batch, V, cin, 1e-5f, mean, rstd, ws, st);
+    int sc1[1] = {cin}, sc3[1] = {cmid};
+    launch_pack_weights(dw1, cmid, cin, 1, sc1, sc1, 1, nullptr, 1, 1.f, s1, pk1, st);
+    launch_pack_weights_wino(dw3, cout, cmid, sc3, sc3, 1, nullptr, 1, 1.f, s3, pk3, st);
+    Conv1Srcs s{};
+    s.n = 1;
+    s.s[0] = Conv1Src{xr, mean, rstd, 1, cin / 16, cin / 16, 0, 1};
+    const SplitView opv{op, cmid / 16, 0, cmid / 16};
+    if (conv1x1_can_emit_wino(dm)) {
+        launch_conv1x1(s, pk1, 0, db1, 1.0f / (s1 * ASCALE_DEFAULT), nullptr, opv, batch, dm, cmid, enc, st);
+    } else {
+        launch_conv1x1(s, pk1, 0, db1, 1.0f / (s1 * ASCALE_DEFAULT), mid, SplitView{nullptr, 0, 0, 0}, batch, dm, cmid, enc, st);
+        launch_prep_wino(mid, batch, dm, cmid, nullptr, nullptr, 0, nullptr, opv, SplitView{nullptr, 0, 0, 0}, nullptr, ws, enc, st);
+    }
+    ConvSrcs cs{};
+    cs.n = 1; cs.p[0] = op; cs.chunks_total[0] = cmid / 16; cs.chunk_off[0] = 0; cs.chunks[0] = cmid / 16;
+    launch_conv_wino(cs, pk3, 0, db3, 1.0f / (s3 * ASCALE_DEFAULT), raw, batch, dm, cout, nullptr, st);
     launch_nhwc_to_nchw(raw, batch, cout, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));
@@ -908,7 +1044,7 @@ int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, 
     HIPC(c, hipMemcpy(dw, wt.data(), sizeof(float) * 27 * ch, hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(db, h_b, sizeof(float) * ch, hipMemcpyHostToDevice));
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
-    launch_depthwise(a, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, nullptr, st);
+    launch_depthwise(a, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, nullptr, nullptr, st);
     launch_nhwc_to_nchw(b, batch, ch, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));

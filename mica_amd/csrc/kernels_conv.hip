@@ -3,7 +3,7 @@
 // of the f32-MFMA cost (MI355X: f32 MFMA 157 TF, f16 2.5 PF).  Replaces nn.Conv3d(k=3,pad=1) / nn.Conv3d(k=1) of reference
 // models/model.py:17,28,38,96,107,115,122,142,158-174,210,212.
 //   conv_wino16_kernel<128|64|32> : every 3^3 conv - Winograd F(2,3) along x, v_mfma_f32_16x16x32_f16, persistent
-//   conv2_kernel<1,...>           : the 1x1x1 convs (direct)
+// (the 1x1x1 convs are in kernels_conv1x1.hip)
 // Also here: weight packing, the depthwise 3^3 conv (model.py:80) and the Cin=1 multi-scale stem (model.py:9-14).
 #include "common.h"
 #include <vector>
@@ -24,232 +24,6 @@ static bool first_use_on_device(unsigned long long& mask) {
     mask |= 1ull << dev;
     return first;
 }
-
-// ================================================================================================
-// conv2 (direct conv; now the 1x1x1 convs only): structured around the measured stalls of the
-// first version (four-wave workgroups staging A and B through LDS per tap: 57 % of the wave-cycles waited at the per-tap
-// barrier / B hand-off; removed from the tree):
-//   * one 8-wave workgroup per CU, output tile 16(x) x 8(y) x 4(z) = 512 GEMM rows x BN channels
-//     (halo overhead 2.1x instead of 2.8x, weights fetched once per 512 rows);
-//   * the halo'd A slab is DOUBLE-buffered in LDS and filled by LDS-DMA (global_load_lds, 16 B/lane, no
-//     VGPR round trip); out-of-volume voxels are never written (exec-masked) and stay zero from a
-//     one-time clear, which implements the conv's zero padding; one barrier per 16-channel chunk;
-//   * weights are not staged in LDS: each wave loads its own B fragments straight from L1/L2 into
-//     registers one step ahead (the packed layout is contiguous in step order), so there is no per-tap
-//     barrier at all;
-//   * waves are arranged WM (rows) x WN (channels): with 4x2 a wave owns 4 row-fragments x 64 channels
-//     (24 MFMAs per tap from 8 ds_read_b128 + 4 global loads).
-// DMA issue is staggered (waves 0-3 at the first tap, waves 4-7 mid-chunk) because vmcnt retires in order:
-// a B-fragment wait behind a freshly issued DMA stalls until the DMA lands, and SIMD partners w / w+4
-// should not do that at the same time.
-// ================================================================================================
-template <int KS> struct Geo2 {
-    static constexpr int HALO = KS / 2;
-    static constexpr int SX = 16 + 2 * HALO, SY = 8 + 2 * HALO, SZ = 4 + 2 * HALO;
-    static constexpr int PZ = ((SX * SY + 63) / 64) * 64;      // slots per z plane: whole DMA instructions
-    static constexpr int PLANE = SZ * PZ;
-    static constexpr int CH_BYTES = 4 * PLANE * 16;           // one chunk image: 4 planes (hi/lo x k-half)
-    static constexpr int CPS = (KS == 3) ? 1 : 2;             // chunks per stage
-    static constexpr int STAGE_BYTES = CPS * CH_BYTES;
-    static constexpr int NT = KS * KS * KS;
-    static constexpr int DPZ = PZ / 64;                       // DMA instructions per (plane, z)
-    static constexpr int DMA_PER_CHUNK = 4 * SZ * DPZ;
-    static constexpr int DPW = DMA_PER_CHUNK / 8;             // per wave
-    static_assert(DMA_PER_CHUNK % 8 == 0, "DMA instructions must split evenly over 8 waves");
-};
-
-template <int DPW>
-__device__ __forceinline__ void issue_chunk_dma(const _Float16* __restrict__ src, char* lds_chunk, const int (&goff)[DPW],
-                                                const int (&loff)[DPW]) {
-#pragma unroll
-    for (int k = 0; k < DPW; ++k)
-        if (goff[k] >= 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + goff[k]),
-                                             (__attribute__((address_space(3))) void*)(lds_chunk + loff[k]), 16, 0, 0);
-}
-
-__device__ __forceinline__ const _Float16* chunk_base(const ConvSrcs& s, int gch, int b, int V) {
-    int si = 0, ch = gch;
-#pragma unroll
-    for (int i = 0; i < MAX_SRC - 1; ++i)
-        if (si == i && i + 1 < s.n && ch >= s.chunks[i]) { ch -= s.chunks[i]; si = i + 1; }
-    return s.p[si] + ((int64_t)b * s.chunks_total[si] + s.chunk_off[si] + ch) * (int64_t)V * 32;
-}
-
-template <int KS, int BN, int WM, int WN>
-__global__ __launch_bounds__(512, 2) void conv2_kernel(ConvSrcs s, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
-                                                       const float* __restrict__ bias, float out_scale,
-                                                       float* __restrict__ out, Dims d, int cout, int total_chunks,
-                                                       int ntx, int nty, int nnb) {
-    using G = Geo2<KS>;
-    static_assert(WM * WN == 8, "8 waves");
-    constexpr int FM = 16 / WM;            // row fragments per wave
-    constexpr int WNC = BN / WN;           // channels per wave
-    constexpr int NJ = WNC / 32;
-    static_assert(NJ >= 1 && FM >= 1, "wave tile");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wn = wave / WM;
-    const int b = blockIdx.y;
-    const int V = d.D * d.H * d.W;
-
-    int id = blockIdx.x;
-    const int nwg = gridDim.x;
-    if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
-    const int nb = id % nnb;
-    const int tile = id / nnb;
-    const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
-    const int x0 = tx * 16 - G::HALO, y0 = ty * 8 - G::HALO, z0 = tz * 4 - G::HALO;
-
-    // one-time clear of both stage buffers (zero padding + never-written pad slots)
-    for (int i = tid; i < 2 * G::STAGE_BYTES / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
-
-    // chunk-invariant DMA descriptors of this wave
-    int goff[G::DPW], loff[G::DPW];
-#pragma unroll
-    for (int k = 0; k < G::DPW; ++k) {
-        const int ii = wave * G::DPW + k;
-        const int q = ii / (G::SZ * G::DPZ), rem = ii % (G::SZ * G::DPZ);
-        const int vz = rem / G::DPZ, part = rem % G::DPZ;
-        const int slot = part * 64 + lane;
-        const int vy = slot / G::SX, vx = slot - vy * G::SX;
-        const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
-        const bool ok = slot < G::SX * G::SY && (unsigned)gx < (unsigned)d.W && (unsigned)gy < (unsigned)d.H &&
-                        (unsigned)gz < (unsigned)d.D;
-        goff[k] = ok ? ((gz * d.H + gy) * d.W + gx) * 32 + q * 8 : -1;
-        loff[k] = (q * G::PLANE + vz * G::PZ + part * 64) * 16;
-    }
-
-    floatx16 acc[FM][NJ];
-#pragma unroll
-    for (int f = 0; f < FM; ++f)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[f][j][i] = 0.f;
-
-    const int lx = lane & 15, lzz = (lane >> 4) & 1, lh = lane >> 5;
-    const int y_w = wm * (FM >= 2 ? FM / 2 : 1);                 // first y row of this wave (FM=4: 2 rows, FM=2: 1 row)
-    const int a_base = (lh * G::PLANE + lzz * G::PZ + y_w * G::SX + lx) * 16;
-    // B fragments come straight from L1/L2: address = wave-uniform byte base (SGPR pair, advanced per step)
-    // + a per-lane 32-bit offset that never changes => global_load saddr+voffset form, no per-tap VALU and no
-    // hoisted per-tap address registers.
-    const char* wuni = reinterpret_cast<const char*>(wpk + (int64_t)b * wpk_bstride) + (int64_t)(nb * BN + wn * WNC) * 16;
-    const unsigned wlane = (unsigned)(lh * cout + (lane & 31)) * 16u;
-    const int64_t bstep = (int64_t)4 * cout * 16;    // bytes per step
-    const int64_t bkind = (int64_t)2 * cout * 16;    // bytes hi-plane -> lo-plane
-    const int nsteps = total_chunks * G::NT;
-    const int nstages = (total_chunks + G::CPS - 1) / G::CPS;
-
-    half8 bnx[NJ][2];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int kind = 0; kind < 2; ++kind) bnx[j][kind] = *reinterpret_cast<const half8*>(wuni + kind * bkind + j * 512 + wlane);
-
-    __syncthreads();   // clear done before any DMA lands
-#pragma unroll
-    for (int c = 0; c < G::CPS; ++c)
-        if (c < total_chunks) issue_chunk_dma<G::DPW>(chunk_base(s, c, b, V), smem + c * G::CH_BYTES, goff, loff);
-    __syncthreads();   // (the compiler drains vmcnt before the barrier)
-
-    int g = 0;
-    for (int st = 0; st < nstages; ++st) {
-        char* cur = smem + (st & 1) * G::STAGE_BYTES;
-        char* nxt = smem + ((st + 1) & 1) * G::STAGE_BYTES;
-        const bool have_next = st + 1 < nstages;
-#pragma unroll
-        for (int c = 0; c < G::CPS; ++c) {
-            const int gch = st * G::CPS + c;
-            if (gch < total_chunks) {
-                const char* A = cur + c * G::CH_BYTES + a_base;
-#pragma unroll
-                for (int tap = 0; tap < G::NT; ++tap, ++g) {
-                    // staggered prefetch of the next stage into the other buffer
-                    if (have_next) {
-                        const int cn = (st + 1) * G::CPS + c;
-                        if (cn < total_chunks) {
-                            if (tap == 0 && wave < 4) issue_chunk_dma<G::DPW>(chunk_base(s, cn, b, V), nxt + c * G::CH_BYTES, goff, loff);
-                            if (tap == (G::NT > 1 ? G::NT / 2 : 0) && wave >= 4)
-                                issue_chunk_dma<G::DPW>(chunk_base(s, cn, b, V), nxt + c * G::CH_BYTES, goff, loff);
-                        }
-                    }
-                    const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-                    half8 bc[NJ][2];
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) { bc[j][0] = bnx[j][0]; bc[j][1] = bnx[j][1]; }
-                    if (g + 1 < nsteps) {
-                        const char* wn_ = wuni + (int64_t)(g + 1) * bstep;
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                            for (int kind = 0; kind < 2; ++kind)
-                                bnx[j][kind] = *reinterpret_cast<const half8*>(wn_ + kind * bkind + j * 512 + wlane);
-                    }
-                    half8 a[FM][2];
-#pragma unroll
-                    for (int f = 0; f < FM; ++f) {
-                        const int yo = (FM == 4) ? (f >> 1) : 0, zp = (FM == 4) ? (f & 1) : f;
-#pragma unroll
-                        for (int kind = 0; kind < 2; ++kind)
-                            a[f][kind] = *reinterpret_cast<const half8*>(
-                                A + (kind * 2 * G::PLANE + (2 * zp + dz) * G::PZ + (yo + dy) * G::SX + dx) * 16);
-                    }
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                        for (int f = 0; f < FM; ++f) {
-                            acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][1], bc[j][0], acc[f][j], 0, 0, 0);
-                            acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bc[j][1], acc[f][j], 0, 0, 0);
-                            acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[f][0], bc[j][0], acc[f][j], 0, 0, 0);
-                        }
-                    // keep the unrolled taps in program order: without this hipcc hoists the B loads of many
-                    // future taps and spills (256 VGPRs + scratch)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        __syncthreads();   // next stage landed (vmcnt drained) and everyone is done reading `cur`
-    }
-
-    const int col = lane & 31, rhalf = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = nb * BN + wn * WNC + j * 32 + col;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int f = 0; f < FM; ++f) {
-            const int yo = (FM == 4) ? (f >> 1) : 0, zp = (FM == 4) ? (f & 1) : f;
-            const int gy = ty * 8 + y_w + yo;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = (i & 3) + 8 * (i >> 2) + 4 * rhalf;
-                const int gx = tx * 16 + (r & 15), gz = tz * 4 + 2 * zp + (r >> 4);
-                if (gx < d.W && gy < d.H && gz < d.D)
-                    out[((int64_t)b * V + (int64_t)(gz * d.H + gy) * d.W + gx) * cout + n] = acc[f][j][i] * out_scale + bv;
-            }
-        }
-    }
-}
-
-template <int KS, int BN, int WM, int WN>
-static void launch_conv2_t(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
-                           float* out, int B, Dims d, int cout, hipStream_t st) {
-    using G = Geo2<KS>;
-    int total = 0;
-    for (int i = 0; i < s.n; ++i) total += s.chunks[i];
-    int ntx = (d.W + 15) / 16, nty = (d.H + 7) / 8, ntz = (d.D + 3) / 4, nnb = cout / BN;
-    size_t lds = 2 * G::STAGE_BYTES;
-    static unsigned long long seen = 0;
-    if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)conv2_kernel<KS, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(ntx * nty * ntz * nnb, B);
-    hipLaunchKernelGGL((conv2_kernel<KS, BN, WM, WN>), grid, dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
-                       cout, total, ntx, nty, nnb);
-}
-
 
 // ================================================================================================
 // conv_wino: dense 3x3x3 conv with Winograd F(2,3) along x on top of the conv2 structure.  The kernel is
@@ -881,17 +655,6 @@ void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_se
                        cout_scale * wscale, wpk, packed_weight_halves_wino(cout, total_chunks), wino16_block(cout));
 }
 
-void launch_conv_mfma(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
-                      float out_scale, float* out, int B, Dims d, int cout, int ksize,
-                      hipStream_t st) {
-    // the 1x1x1 convs (3^3 goes through launch_conv_wino); cout is always a multiple of 32 here (small heads go through
-    // launch_head_final)
-    (void)ksize;
-    if (cout % 128 == 0) launch_conv2_t<1, 128, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-    else if (cout % 64 == 0) launch_conv2_t<1, 64, 4, 2>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-    else launch_conv2_t<1, 32, 8, 1>(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, st);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Weight packing: torch [Cout][Cin][k][k][k] f32 -> [B][chunk][tap][q][Cout][8] halves, q = kind*2+khalf.
 // Input channels are laid out as the concatenation of the conv's sources, each padded to 16.
@@ -981,7 +744,7 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ scale, const float* __restrict__ w27,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        float* __restrict__ stats_ws, int ntx, int nty) {
+                                                        float* __restrict__ stats_ws, float* __restrict__ gap_ws, int ntx, int nty) {
     extern __shared__ __attribute__((aligned(16))) float ring[];   // [3][LY][LX][16] ; reused for the statistics merge
     constexpr int DW_Y = DwGeo<YO, CQ>::Y, DW_LY = DwGeo<YO, CQ>::LY, DW_PLANE = DwGeo<YO, CQ>::PLANE, DW_C = 4 * CQ, NT = 64 * CQ;
     const int b = blockIdx.y;
@@ -1024,6 +787,9 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
             pre[k] = *reinterpret_cast<const float4*>(x + ((int64_t)b * V + (int64_t)(cz * d.H + cy) * d.W + cx) * C + c0 + lq * 4);
         }
     };
+    // gap_ws: the global average pool of the NORMALISED input (the SE gate's input, model.py:256) rides along: every voxel is an
+    // interior element of exactly one block
+    float4 gsum = make_float4(0, 0, 0, 0);
     auto store_plane = [&](int slot, int gz, float4 (&pre)[NE]) {
         float* dst = ring + slot * DW_PLANE;
         const bool zok = (unsigned)gz < (unsigned)d.D;
@@ -1039,7 +805,10 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
                 t.z = fmaxf((t.z - nm.z) * nr.z, 0.f) * ns.z; t.w = fmaxf((t.w - nm.w) * nr.w, 0.f) * ns.w;
             } else { t.x *= ns.x; t.y *= ns.y; t.z *= ns.z; t.w *= ns.w; }
             if (!ok) t = make_float4(0, 0, 0, 0);
-            if (e < DW_LX * DW_LY * CQ) *reinterpret_cast<float4*>(dst + v * DW_C + lq * 4) = t;
+            if (e < DW_LX * DW_LY * CQ) {
+                *reinterpret_cast<float4*>(dst + v * DW_C + lq * 4) = t;
+                if (lx >= 1 && lx <= DW_X && ly >= 1 && ly <= DW_Y) { gsum.x += t.x; gsum.y += t.y; gsum.z += t.z; gsum.w += t.w; }
+            }
         }
     };
 
@@ -1108,6 +877,24 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
         store_plane((z + 2) % 3, z + 4, preC);
         __syncthreads();
     }
+    if (gap_ws) {
+        // block sum per channel: the 64 threads that share a channel quad, fixed tree
+        __syncthreads();
+        float4* sg = reinterpret_cast<float4*>(ring);
+        sg[tid] = gsum;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) {
+            if (tid / CQ < off) {
+                const float4 o = sg[tid + off * CQ];
+                float4 a = sg[tid];
+                a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+                sg[tid] = a;
+            }
+            __syncthreads();
+        }
+        if (tid / CQ == 0) *reinterpret_cast<float4*>(gap_ws + ((int64_t)b * ncol + col) * C + c0 + (tid % CQ) * 4) = sg[tid];
+        __syncthreads();
+    }
     if (!stats_ws) return;
     // block merge of (count, mean, M2): 64 threads (x, yq) share a channel quad
     float* shn = ring; float* shm = ring + 4 * NT; float* shq = ring + 8 * NT;
@@ -1146,30 +933,30 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null).
 template <int YO, int CQ>
 static void launch_depthwise_t(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, const float* scale,
-                               const float* w27, const float* bias, float* out, float* stats_ws, int ntx, int nty, hipStream_t st) {
+                               const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, int ntx, int nty, hipStream_t st) {
     using Gm = DwGeo<YO, CQ>;
     const size_t lds = (3 * Gm::PLANE + 27 * Gm::DWC) * sizeof(float);
     static unsigned long long seen = 0;
     if (first_use_on_device(seen))
         (void)hipFuncSetAttribute((const void*)depthwise_kernel<YO, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)(ntx * nty * (C / Gm::DWC)), B);
-    hipLaunchKernelGGL((depthwise_kernel<YO, CQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty);
+    hipLaunchKernelGGL((depthwise_kernel<YO, CQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty);
 }
 int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
-                     const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, hipStream_t st) {
+                     const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st) {
     const int ntx = (d.W + DW_X - 1) / DW_X;
     // 32-channel workgroups (full 128-B lines) when that still gives every CU at least two rounds of work
     if (C % 32 == 0 && (int64_t)ntx * ((d.H + 15) / 16) * (C / 32) * B >= 512) {
         const int nty = (d.H + 15) / 16;
-        launch_depthwise_t<4, 8>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty, st);
+        launch_depthwise_t<4, 8>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, st);
         return ntx * nty;
     }
     // enough workgroups to fill 256 CUs twice: halve the column height when C * batch is small
     const bool small = (int64_t)ntx * ((d.H + 15) / 16) * (C / 16) * B < 1024;
     const int Y = small ? 8 : 16;
     const int nty = (d.H + Y - 1) / Y;
-    if (small) launch_depthwise_t<2, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty, st);
-    else launch_depthwise_t<4, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, ntx, nty, st);
+    if (small) launch_depthwise_t<2, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, st);
+    else launch_depthwise_t<4, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, st);
     return ntx * nty;
 }
 

@@ -1,0 +1,294 @@
+// The 1x1x1 convolutions (reference models/model.py:28 exp_downsizing, :38 fusion, :96 dual_attn.fusion, :158-160 FPN laterals)
+// as one streaming GEMM kernel whose prologue and epilogue replace the operand passes around it.
+//
+// These layers are HBM-bound (1.7 % of the FLOPs, arithmetic intensity 20-85 FLOP/B), and every one of them sits between
+// two re-encoding passes in the first version of the graph: its inputs were InstanceNorm-applied, ReLU'd and split into
+// f16 hi/lo by a prep pass (read 4 B + write 4 B per value), and its f32 output went through another pass to become the
+// Winograd operand of the 3x3x3 conv that follows (read 4 B + write 8 B).  Here
+//   * a source may be the RAW f32 output of the producing conv together with its InstanceNorm constants: the
+//     normalisation, the ReLU and the hi/lo split happen while the tile is staged into LDS (VALU work the kernel has to
+//     spare: it waits on HBM) - or an operand that already is in split form (stem output, gated AF3 features);
+//   * the epilogue writes the consumer's operand directly: the Winograd F(2,3) input transform along x needs the two
+//     x-neighbours of every output pair, and a workgroup owns whole x rows (W <= 64), so the neighbours are either in its
+//     own tile or outside the volume (= the consumer's zero padding).  Raw f32 output is there for the single-op entry point
+//     and for tile widths that do not divide the 256-voxel tile.
+//
+// Arithmetic: split-f16 products as in the 3x3x3 kernel, x*w = a_hi*b_hi + a_lo*b_hi + a_hi*b_lo with f32 accumulation, on
+// v_mfma_f32_16x16x32_f16: per PAIR of 16-channel chunks (c, c') three instructions per 16x16 tile,
+//   X(c)  : A = [a_hi(c) | a_lo(c)]   B = [b_hi(c) ; b_hi(c)]          X(c') likewise
+//   Y     : A = [a_hi(c) | a_hi(c')]  B = [b_lo(c) ; b_lo(c')]
+// Workgroup: 8 waves, 256 voxels x Cout; wave (wm, wn) owns 128 voxels (8 row fragments) x the column tiles {wn + 4 j}.
+// LDS: two 32-KB stages of [chunk-in-pair 2][plane 4 = hi/lo x channel half][256 rows] 16-byte slots (a ds_read_b128 lane
+// group covers 16 consecutive slots), refilled one pair ahead: global loads for pair p+1 are issued before the MFMAs of
+// pair p and committed to LDS after them, one barrier per pair.
+#include "common.h"
+
+namespace mica {
+
+typedef float floatx4c __attribute__((ext_vector_type(4)));
+
+constexpr int C1_ROWS = 256;
+constexpr int C1_STAGE = 2 * 4 * C1_ROWS * 16;          // bytes per stage
+constexpr int C1_TS = 68;                               // floats per row of the epilogue staging tile (64 + pad)
+constexpr int C1_TBYTES = C1_ROWS * C1_TS * 4;
+constexpr int C1_TAB = 2 * 512 * 2 * 4;                 // (mean, rstd) of up to 512 channels for two sources
+constexpr int C1_LDS = (C1_TBYTES > 2 * C1_STAGE ? C1_TBYTES : 2 * C1_STAGE) + C1_TAB;
+
+__device__ __forceinline__ void c1_split8(const float (&y)[8], half8& hi, half8& lo, int& bad, float ascale) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float xs = y[j] * ascale;
+        if (!(fabsf(xs) <= F16_LIMIT)) {          // flag, and saturate so that an overflow cannot turn into Inf/NaN downstream
+            bad |= (fabsf(y[j]) <= 3.0e38f) ? RANGE_OVERFLOW : RANGE_NONFINITE;
+            xs = fminf(fmaxf(xs, -F16_LIMIT), F16_LIMIT);
+        }
+        const _Float16 h = (_Float16)xs;
+        hi[j] = h;
+        lo[j] = (_Float16)(xs - (float)h);
+    }
+}
+
+template <int NCT, bool WINO>
+__global__ __launch_bounds__(512) void conv1x1_kernel(Conv1Srcs src, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
+                                                      const float* __restrict__ bias, float out_scale, float* __restrict__ out_raw,
+                                                      SplitView wino, Dims d, int cout, int total_chunks, SplitEnc enc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* tab = reinterpret_cast<float2*>(smem + C1_LDS - C1_TAB);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int b = blockIdx.y;
+    const int V = d.D * d.H * d.W;
+    const int v0 = blockIdx.x * C1_ROWS;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // InstanceNorm constants of the raw sources
+    for (int si = 0; si < src.n; ++si) {
+        const Conv1Src& s = src.s[si];
+        if (s.kind == 1) {
+            const int Cs = s.chunks_total * 16;
+            for (int ch = tid; ch < Cs; ch += 512)
+                tab[si * 512 + ch] = s.mean ? make_float2(s.mean[(int64_t)b * Cs + ch], s.rstd[(int64_t)b * Cs + ch]) : make_float2(0.f, 1.f);
+        }
+    }
+
+    // ---- staging of one chunk pair: fetch (global -> registers), commit (registers -> LDS, normalising raw sources) ----
+    struct Where { int si, lc; };
+    auto where = [&](int gch) {
+        Where w{0, gch};
+        if (src.n > 1 && gch >= src.s[0].chunks) { w.si = 1; w.lc = gch - src.s[0].chunks; }
+        return w;
+    };
+    float4 st[2][2];
+    auto fetch = [&](int pair) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int gch = 2 * pair + cc;
+            st[cc][0] = st[cc][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gch >= total_chunks) continue;
+            const Where w = where(gch);
+            const Conv1Src& s = src.s[w.si];
+            if (s.kind == 1) {                               // raw: item = (row, 8-channel half)
+                const int row = tid >> 1, kh = tid & 1;
+                const int v = v0 + row;
+                if (v < V) {
+                    const float* p = reinterpret_cast<const float*>(s.p) + ((int64_t)b * V + v) * (s.chunks_total * 16) + (s.chunk_off + w.lc) * 16 + kh * 8;
+                    st[cc][0] = *reinterpret_cast<const float4*>(p);
+                    st[cc][1] = *reinterpret_cast<const float4*>(p + 4);
+                }
+            } else {                                          // split: two 16-byte pieces, piece = (row, plane)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int id = tid + 512 * k, plane = id & 3, row = id >> 2;
+                    const int v = v0 + row;
+                    if (v < V)
+                        st[cc][k] = *reinterpret_cast<const float4*>(reinterpret_cast<const _Float16*>(s.p) +
+                                                                     (((int64_t)b * s.chunks_total + s.chunk_off + w.lc) * V + v) * 32 + plane * 8);
+                }
+            }
+        }
+    };
+    int bad = 0;
+    auto commit = [&](int pair, char* buf) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int gch = 2 * pair + cc;
+            const Where w = where(gch < total_chunks ? gch : 0);
+            const Conv1Src& s = src.s[w.si];
+            char* cb = buf + cc * (4 * C1_ROWS * 16);
+            if (gch < total_chunks && s.kind == 1) {
+                const int row = tid >> 1, kh = tid & 1;
+                const int ch0 = (s.chunk_off + w.lc) * 16 + kh * 8;
+                float y[8] = {st[cc][0].x, st[cc][0].y, st[cc][0].z, st[cc][0].w, st[cc][1].x, st[cc][1].y, st[cc][1].z, st[cc][1].w};
+                const bool live = v0 + row < V;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float2 mr = tab[w.si * 512 + ch0 + j];
+                    float t = (y[j] - mr.x) * mr.y;
+                    if (s.relu) t = fmaxf(t, 0.f);
+                    y[j] = live ? t : 0.f;
+                }
+                half8 hi, lo;
+                c1_split8(y, hi, lo, bad, enc.ascale);
+                *reinterpret_cast<half8*>(cb + ((kh)*C1_ROWS + row) * 16) = hi;
+                *reinterpret_cast<half8*>(cb + ((2 + kh) * C1_ROWS + row) * 16) = lo;
+            } else {                                          // split source, or the missing second chunk of an odd count (zeros)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int id = tid + 512 * k, plane = id & 3, row = id >> 2;
+                    *reinterpret_cast<float4*>(cb + (plane * C1_ROWS + row) * 16) = st[cc][k];
+                }
+            }
+        }
+    };
+
+    floatx4c acc[8][NCT];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[f][c][i] = 0.f;
+
+    const int npairs = (total_chunks + 1) >> 1;
+    const _Float16* wb = wpk + (int64_t)b * wpk_bstride;
+    const int rowbase = wm * 128 + lr;
+
+    __syncthreads();                                  // norm table ready
+    fetch(0);
+    commit(0, smem);
+    for (int p = 0; p < npairs; ++p) {
+        char* cur = smem + (p & 1) * C1_STAGE;
+        if (p + 1 < npairs) fetch(p + 1);
+        __syncthreads();                              // stage p is complete; nobody still reads the stage that commit(p+1) will overwrite
+        const int c0 = 2 * p, c1 = (2 * p + 1 < total_chunks) ? 2 * p + 1 : 2 * p;
+#pragma unroll
+        for (int kind = 0; kind < 3; ++kind) {        // 0: X(c), 1: X(c'), 2: Y
+            if (kind == 1 && 2 * p + 1 >= total_chunks) continue;
+            half8 bq[NCT];
+            {
+                const int gc = kind == 0 ? c0 : kind == 1 ? c1 : ((lg >> 1) ? c1 : c0);
+                const int q = (kind == 2 ? 2 : 0) + (lg & 1);
+                const _Float16* wp = wb + ((int64_t)(gc * 4 + q) * cout + wn * 16 + lr) * 8;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) bq[c] = *reinterpret_cast<const half8*>(wp + (int64_t)c * 64 * 8);
+            }
+            // A: X(cc) reads plane lg of chunk cc; Y reads the hi plane (lg & 1) of chunk (lg >> 1)
+            const int aplane = kind == 0 ? lg : kind == 1 ? 4 + lg : (lg >> 1) * 4 + (lg & 1);
+            const char* ap = cur + (aplane * C1_ROWS + rowbase) * 16;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                const half8 a = *reinterpret_cast<const half8*>(ap + f * 16 * 16);
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[c], acc[f][c], 0, 0, 0);
+            }
+        }
+        if (p + 1 < npairs) commit(p + 1, smem + ((p + 1) & 1) * C1_STAGE);
+    }
+    if (bad) atomicOr(enc.err, bad);
+
+    // ---- epilogue: 64 output channels per pass through the staging tile T[256][64 (+4)] ----
+    float* T = reinterpret_cast<float*>(smem);
+    const int Wh = (d.W + 1) >> 1, Vh = d.D * d.H * Wh;
+    int bad2 = 0;
+#pragma unroll
+    for (int pass = 0; pass < NCT; ++pass) {
+        __syncthreads();                              // MFMA phase (or the previous pass's readers) done with this LDS
+        {
+            const int n = (pass * 4 + wn) * 16 + lr;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int f = 0; f < 8; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)           // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + i
+                    T[(wm * 128 + f * 16 + lg * 4 + i) * C1_TS + wn * 16 + lr] = acc[f][pass][i] * out_scale + bv;
+        }
+        __syncthreads();
+        if (!WINO) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int id = it * 512 + tid, cg = id & 15, row = id >> 4;
+                const int v = v0 + row;
+                if (v < V)
+                    *reinterpret_cast<float4*>(out_raw + ((int64_t)b * V + v) * cout + pass * 64 + cg * 4) =
+                        *reinterpret_cast<const float4*>(T + row * C1_TS + cg * 4);
+            }
+        } else {
+            // Winograd input transform of the consumer (kernels_elem.hip: prep_wino_kernel): per output pair (x = 2i, 2i+1) and
+            // d_k = y(2i-1+k), zero outside the row:  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int id = it * 512 + tid, phl = id & 127, kg = id >> 7;
+                const int yr = phl / Wh, i = phl - yr * Wh;
+                const int vrow = v0 + yr * d.W;       // first voxel of this x row
+                if (vrow < V) {
+                    float dv[4][8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int xx = 2 * i - 1 + k;
+                        const bool ok = (unsigned)xx < (unsigned)d.W;
+                        const float* tp = T + (yr * d.W + (ok ? xx : 0)) * C1_TS + kg * 8;
+                        const float4 a = *reinterpret_cast<const float4*>(tp), c = *reinterpret_cast<const float4*>(tp + 4);
+                        dv[k][0] = ok ? a.x : 0.f; dv[k][1] = ok ? a.y : 0.f; dv[k][2] = ok ? a.z : 0.f; dv[k][3] = ok ? a.w : 0.f;
+                        dv[k][4] = ok ? c.x : 0.f; dv[k][5] = ok ? c.y : 0.f; dv[k][6] = ok ? c.z : 0.f; dv[k][7] = ok ? c.w : 0.f;
+                    }
+                    float t[4][8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        t[0][j] = dv[0][j] - dv[2][j];
+                        t[1][j] = dv[1][j] + dv[2][j];
+                        t[2][j] = dv[2][j] - dv[1][j];
+                        t[3][j] = dv[1][j] - dv[3][j];
+                    }
+                    const int chunk = pass * 4 + (kg >> 1), kh = kg & 1;
+                    const int64_t ph = (int64_t)(vrow / d.W) * Wh + i;
+                    _Float16* wbp = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + chunk) * 4 * Vh) * 32;
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        half8 hi, lo;
+                        c1_split8(t[pp], hi, lo, bad2, enc.ascale);
+                        *reinterpret_cast<half8*>(wbp + ((int64_t)(pp * 4 + kh) * Vh + ph) * 8) = hi;
+                        *reinterpret_cast<half8*>(wbp + ((int64_t)(pp * 4 + 2 + kh) * Vh + ph) * 8) = lo;
+                    }
+                }
+            }
+        }
+    }
+    if (bad2) atomicOr(enc.err, bad2);
+}
+
+bool conv1x1_can_emit_wino(Dims d) { return d.W >= 2 && d.W <= 64 && C1_ROWS % d.W == 0 && (d.W & 1) == 0; }
+
+template <int NCT, bool WINO>
+static void launch_conv1x1_t(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
+                             float* out_raw, SplitView wino, int B, Dims d, int cout, int total, SplitEnc enc, hipStream_t st) {
+    static unsigned long long seen = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !(seen >> dev & 1ull)) {
+        seen |= 1ull << dev;
+        (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCT, WINO>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS);
+    }
+    const int V = d.D * d.H * d.W;
+    dim3 grid((V + C1_ROWS - 1) / C1_ROWS, B);
+    hipLaunchKernelGGL((conv1x1_kernel<NCT, WINO>), grid, dim3(512), C1_LDS, st, src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, d, cout,
+                       total, enc);
+}
+
+// cout in {64, 128, 256}.  Exactly one of out_raw / wino.p is given; wino needs conv1x1_can_emit_wino(d).
+void launch_conv1x1(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out_raw,
+                    SplitView wino, int B, Dims d, int cout, SplitEnc enc, hipStream_t st) {
+    int total = 0;
+    for (int i = 0; i < src.n; ++i) total += src.s[i].chunks;
+    const bool w = wino.p != nullptr;
+#define C1_GO(NCT)                                                                                                          \
+    do {                                                                                                                    \
+        if (w) launch_conv1x1_t<NCT, true>(src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, B, d, cout, total, enc, st);  \
+        else launch_conv1x1_t<NCT, false>(src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, B, d, cout, total, enc, st);   \
+    } while (0)
+    if (cout == 64) C1_GO(1);
+    else if (cout == 128) C1_GO(2);
+    else C1_GO(4);
+#undef C1_GO
+}
+
+}  // namespace mica

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
 // channels x 64 slot lanes: for a given slot the 4 channels are 48 contiguous bytes (one block per channel read its
 // 12-byte triples at a stride of C * 12 bytes: 64-B sectors for 12 useful bytes).
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ ws, int nblk, int C, float eps,
-                                                             float* __restrict__ mean, float* __restrict__ rstd) {
+                                                             float* __restrict__ mean, float* __restrict__ rstd,
+                                                             const float* __restrict__ gate) {
     __shared__ double sn[256], sm[256], sq[256];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cl = tid & 3, sl = tid >> 2, c = blockIdx.x * 4 + cl;
@@ -123,13 +124,14 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
     }
     if (sl == 0 && c < C) {
         mean[(int64_t)b * C + c] = (float)sm[tid];
-        rstd[(int64_t)b * C + c] = (float)(1.0 / sqrt(sq[tid] / sn[tid] + (double)eps));
+        const double g = gate ? (double)gate[(int64_t)b * C + c] : 1.0;
+        rstd[(int64_t)b * C + c] = (float)(g / sqrt(g * g * (sq[tid] / sn[tid]) + (double)eps));
     }
 }
 
 int64_t stats_ws_floats(int B, int C) { return (int64_t)B * RED_BLOCKS * C * 3; }
-void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, float* mean, float* rstd, hipStream_t st) {
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd);
+void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, float* mean, float* rstd, hipStream_t st, const float* gate) {
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd, gate);
 }
 // fused statistics: conv_wino writes 4 partials per 16x4x4 output tile (8 for Cout = 32), depthwise one per block
 int64_t fused_stats_ws_floats(int B, int S) {
@@ -145,7 +147,7 @@ void launch_stats(const float* x, int B, int V, int C, float eps, float* mean, f
     int G = C / 8, SUB = 256 / G;
     int nblk = pick_blocks(V, SUB * 8, RED_BLOCKS);
     hipLaunchKernelGGL(stats_kernel, dim3(nblk, B), dim3(256), 3 * 256 * 8 * sizeof(float), st, x, V, C, ws);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd, (const float*)nullptr);
 }
 
 __global__ __launch_bounds__(256) void finalize_sum_kernel(const float* __restrict__ ws, int nblocks, int C, float inv,
@@ -176,7 +178,10 @@ __device__ __forceinline__ void split8(const float (&y)[8], half8& hi, half8& lo
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float xs = y[j] * ascale;
-        if (!(fabsf(xs) <= F16_LIMIT)) bad |= (fabsf(y[j]) <= 3.0e38f) ? RANGE_OVERFLOW : RANGE_NONFINITE;
+        if (!(fabsf(xs) <= F16_LIMIT)) {          // flag, and saturate so that an overflow cannot turn into Inf/NaN downstream
+            bad |= (fabsf(y[j]) <= 3.0e38f) ? RANGE_OVERFLOW : RANGE_NONFINITE;
+            xs = fminf(fmaxf(xs, -F16_LIMIT), F16_LIMIT);
+        }
         _Float16 h = (_Float16)xs;
         hi[j] = h;
         lo[j] = (_Float16)(xs - (float)h);
@@ -630,33 +635,42 @@ __device__ __forceinline__ float softmax3_last(float a, float c, float e) {
 __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ bb, const float* __restrict__ ca,
                                                           const float* __restrict__ aa, int V, float* __restrict__ bbp,
                                                           float* __restrict__ cap, float* __restrict__ aap,
-                                                          float* __restrict__ aapred) {
+                                                          float* __restrict__ aapred, int64_t s1, int64_t s20) {
+    // s1 / s20: elements between batch entries of the single-channel outputs / of the 20-channel output (V and 20 V for
+    // four separate tensors; 23 V each when the four are slices of one record tensor [B][23][V])
     const int b = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
     const float* pb = bb + (int64_t)b * 4 * V + v;
     const float* pc = ca + (int64_t)b * 4 * V + v;
-    bbp[(int64_t)b * V + v] = softmax3_last(pb[0], pb[2 * (int64_t)V], pb[3 * (int64_t)V]);
-    cap[(int64_t)b * V + v] = softmax3_last(pc[0], pc[2 * (int64_t)V], pc[3 * (int64_t)V]);
+    bbp[(int64_t)b * s1 + v] = softmax3_last(pb[0], pb[2 * (int64_t)V], pb[3 * (int64_t)V]);
+    cap[(int64_t)b * s1 + v] = softmax3_last(pc[0], pc[2 * (int64_t)V], pc[3 * (int64_t)V]);
     const float* pa = aa + (int64_t)b * 21 * V + v;
     float l[20];
     float m = -INFINITY;
-    int am = 0;
 #pragma unroll
     for (int j = 0; j < 20; ++j) {
         l[j] = pa[(int64_t)(j + 1) * V];
-        if (l[j] > m) { m = l[j]; am = j; }
+        m = fmaxf(m, l[j]);
     }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 20; ++j) { l[j] = expf(l[j] - m); s += l[j]; }
+    // torch.max(aa_scores, 1)[1] (predict.py:349): the first maximum of the softmax SCORES - two logits that round to the same
+    // score resolve to the lower class, as in the reference
+    float best = -1.f;
+    int am = 0;
 #pragma unroll
-    for (int j = 0; j < 20; ++j) aap[((int64_t)b * 20 + j) * V + v] = l[j] / s;
-    aapred[(int64_t)b * V + v] = (float)am;
+    for (int j = 0; j < 20; ++j) {
+        const float pj = l[j] / s;
+        aap[(int64_t)b * s20 + (int64_t)j * V + v] = pj;
+        if (pj > best) { best = pj; am = j; }
+    }
+    aapred[(int64_t)b * s1 + v] = (float)am;
 }
 void launch_postprocess(const float* bb, const float* ca, const float* aa, int B, int V, float* bbp, float* cap,
-                        float* aap, float* aapred, hipStream_t st) {
-    hipLaunchKernelGGL(postprocess_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, bb, ca, aa, V, bbp, cap, aap, aapred);
+                        float* aap, float* aapred, int64_t s1, int64_t s20, hipStream_t st) {
+    hipLaunchKernelGGL(postprocess_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, bb, ca, aa, V, bbp, cap, aap, aapred, s1, s20);
 }
 
 __global__ void fill_float_kernel(float* p, int64_t n, float v) {

@@ -119,6 +119,23 @@ class Engine:
                 _ptr(pred[b0:b1]), self._stream()), "mica_forward_tiles")
         return out
 
+    def forward_records(self, map_tiles: torch.Tensor, af_tiles: torch.Tensor | None, rec: torch.Tensor, af_mode: int = AF_PER_TILE):
+        """As forward_tiles, written straight into rec f32[T,23,S,S,S] (bb, ca, aa_pred, aa_prob x20 per tile): the record layout
+        stitch_tiles and the multi-GPU exchange use."""
+        S = self.tile_size
+        T = map_tiles.shape[0]
+        map_tiles = _f32c(map_tiles, "map_tiles").view(T, 1, S, S, S)
+        if af_tiles is not None:
+            af_tiles = _f32c(af_tiles, "af_tiles").view(T, 24, S, S, S)
+        if rec.dtype != torch.float32 or not rec.is_cuda or not rec.is_contiguous() or tuple(rec.shape) != (T, 23, S, S, S):
+            raise MicaHipError(f"rec must be a contiguous float32 CUDA(HIP) tensor [{T},23,{S},{S},{S}]")
+        for b0 in range(0, T, self.max_batch):
+            b1 = min(T, b0 + self.max_batch)
+            self._check(self.lib.mica_forward_records(
+                self._h, _ptr(map_tiles[b0:b1]), _ptr(af_tiles[b0:b1]) if af_tiles is not None else None, b1 - b0,
+                af_mode if af_tiles is not None else AF_NONE, _ptr(rec[b0:b1]), self._stream()), "mica_forward_records")
+        return rec
+
     def postprocess(self, bb, ca, aa):
         B = bb.shape[0]
         S = self.tile_size
@@ -235,6 +252,41 @@ class Engine:
                                                     _ptr(ok), self._stream()), "mica_refine_candidates")
         return coord, aao, ok.bool()
 
+    def segment_sums(self, vals: torch.Tensor, seg_off: torch.Tensor) -> torch.Tensor:
+        """modeler.py:776-787: np.sum of every segment vals[seg_off[s]:seg_off[s+1]] in numpy's float32 summation order."""
+        vals = _f32c(vals, "vals")
+        if seg_off.dtype != torch.int64 or not seg_off.is_cuda or seg_off.dim() != 1 or seg_off.numel() < 1:
+            raise MicaHipError("seg_off: expected an int64 CUDA(HIP) vector of nseg + 1 offsets")
+        seg_off = seg_off.contiguous()
+        nseg = seg_off.numel() - 1
+        out = torch.empty((nseg,), dtype=torch.float32, device=self.device)
+        self._check(self.lib.mica_segment_sums(self._h, _ptr(vals), _ptr(seg_off), nseg, _ptr(out), self._stream()), "mica_segment_sums")
+        return out
+
+    def nms_points(self, pts: torch.Tensor, shape, radius: float) -> torch.Tensor:
+        """modeler.py:822-831 over candidates sorted by descending score: pts int32[n,3] -> bool[n] (kept)."""
+        if pts.dtype != torch.int32 or not pts.is_cuda or pts.dim() != 2 or pts.shape[1] != 3:
+            raise MicaHipError("pts: expected an int32 CUDA(HIP) tensor [n,3]")
+        pts = pts.contiguous()
+        n = pts.shape[0]
+        keep = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.mica_nms_points(self._h, _ptr(pts), n, *[int(v) for v in shape], float(radius), _ptr(keep), self._stream()),
+                    "mica_nms_points")
+        return keep.bool()
+
+    def neighbour_matrix(self, cands: torch.Tensor, bb: torch.Tensor):
+        """modeler.py:860-888: cands f64[n,3], bb f32[N0,N1,N2] -> (cand_self_dis f64[n,n], neigh_mat f64[n,n]) on the device."""
+        bb = _f32c(bb, "bb")
+        if cands.dtype != torch.float64 or not cands.is_cuda or cands.dim() != 2 or cands.shape[1] != 3:
+            raise MicaHipError("cands: expected a float64 CUDA(HIP) tensor [n,3]")
+        cands = cands.contiguous()
+        n = cands.shape[0]
+        dis = torch.empty((n, n), dtype=torch.float64, device=self.device)
+        mat = torch.empty((n, n), dtype=torch.float64, device=self.device)
+        self._check(self.lib.mica_neighbour_matrix(self._h, _ptr(cands), n, _ptr(bb), *bb.shape, _ptr(dis), _ptr(mat), self._stream()),
+                    "mica_neighbour_matrix")
+        return dis, mat
+
     # -- single ops (tests) -----------------------------------------------------------------------------
     def op_conv3d(self, x, w, b, k):
         x = _f32c(x, "x")
@@ -245,6 +297,18 @@ class Engine:
         y = torch.empty((B, cout, d, h, ww), dtype=torch.float32, device=self.device)
         self._check(self.lib.mica_op_conv3d(self._h, _ptr(x), B, cin, d, h, ww, w.ctypes.data_as(_cabi._FP),
                                             b.ctypes.data_as(_cabi._FP), cout, k, _ptr(y), self._stream()), "mica_op_conv3d")
+        return y
+
+    def op_norm_conv1_conv3(self, x, w1, b1, w3, b3):
+        """conv3x3x3(conv1x1x1(relu(instance_norm(x)))) through the fused 1x1 kernel (raw source, Winograd-operand epilogue)."""
+        x = _f32c(x, "x")
+        B, cin, d, h, ww = x.shape
+        w1, b1, w3, b3 = (np.ascontiguousarray(a, dtype=np.float32) for a in (w1, b1, w3, b3))
+        cmid, cout = w1.shape[0], w3.shape[0]
+        y = torch.empty((B, cout, d, h, ww), dtype=torch.float32, device=self.device)
+        fp = lambda a: a.ctypes.data_as(_cabi._FP)
+        self._check(self.lib.mica_op_norm_conv1_conv3(self._h, _ptr(x), B, cin, d, h, ww, fp(w1), fp(b1), cmid, fp(w3), fp(b3), cout, _ptr(y),
+                                                      self._stream()), "mica_op_norm_conv1_conv3")
         return y
 
     def op_instnorm_relu(self, x):

@@ -36,15 +36,8 @@ class VolumePredictor:
         at = None
         if af_vol is not None:
             at = e.gather_tiles(af_vol, self.grid, self.pad, first, count, out=self._af_tiles[:count])
-        rec = self._rec[:count]
-        # forward writes straight into the record's channel slices: not contiguous per tensor, so use staging views
         S = e.tile_size
-        bbp, cap, aap, pred = e.forward_tiles(mt.view(count, S, S, S), at, af_mode=AF_PER_TILE)
-        rec[:, 0] = bbp
-        rec[:, 1] = cap
-        rec[:, 2] = pred
-        rec[:, 3:] = aap
-        return rec
+        return e.forward_records(mt.view(count, S, S, S), at, self._rec[:count], af_mode=AF_PER_TILE)
 
     def predict_volume(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None):
         """vol f32[N0,N1,N2] on the GPU (already normalised, (x,y,z) order), af_vol f32[24,N0,N1,N2] or None.

@@ -123,9 +123,7 @@ class CryoEMPredictor:
                     x = torch.from_numpy(np.stack([it[0] for it in items])).to(e.device)
                     af = torch.from_numpy(np.stack([it[1] for it in items])).to(e.device)
                     n = len(grp)
-                    bbp, cap, aap, pred = e.forward_tiles(x.view(n, S, S, S), af, af_mode=AF_BATCH)
-                    rec[:n, 0], rec[:n, 1], rec[:n, 2] = bbp, cap, pred
-                    rec[:n, 3:] = aap
+                    e.forward_records(x.view(n, S, S, S), af, rec[:n], af_mode=AF_BATCH)
                     for q, t in enumerate(grp):
                         e.stitch_tiles(rec[q:q + 1], out, grid, pad, tindex(t))
                 pos = len(order)
@@ -138,9 +136,7 @@ class CryoEMPredictor:
                 afh = np.stack([it[1] for it in items])
                 af = torch.from_numpy(afh).to(e.device) if np.any(afh) else None
                 n = len(run)
-                bbp, cap, aap, pred = e.forward_tiles(x.view(n, S, S, S), af, af_mode=AF_PER_TILE)
-                rec[:n, 0], rec[:n, 1], rec[:n, 2] = bbp, cap, pred
-                rec[:n, 3:] = aap
+                e.forward_records(x.view(n, S, S, S), af, rec[:n], af_mode=AF_PER_TILE)
                 e.stitch_tiles(rec[:n], out, grid, pad, tindex(run[0]))
                 pos += n
             vols = {"backbone_probability": out[0].cpu().numpy(), "carbon_alpha_probability": out[1].cpu().numpy(),

@@ -34,7 +34,7 @@ def _rand(shape, seed, lo=-1.0, hi=1.0):
 
 @pytest.mark.parametrize("cin,cout,k,dims", [
     (16, 32, 3, (8, 8, 8)), (24, 64, 3, (8, 8, 16)), (64, 128, 3, (6, 10, 20)), (196, 64, 3, (8, 8, 8)),
-    (96, 32, 3, (16, 16, 16)), (128, 64, 1, (8, 8, 8)), (192, 64, 1, (4, 12, 9)), (512, 256, 1, (8, 8, 8)),
+    (96, 32, 3, (16, 16, 16)), (128, 64, 1, (8, 8, 8)), (192, 64, 1, (4, 12, 9)), (512, 256, 1, (8, 8, 8)), (48, 128, 1, (7, 8, 8)), (20, 64, 1, (3, 5, 7)),
     (32, 256, 3, (8, 8, 8)), (40, 128, 3, (5, 7, 9)), (144, 256, 3, (12, 6, 18)), (48, 192, 3, (6, 9, 14)), (40, 96, 3, (7, 9, 12)),     # 128 / 64 / 32 blocks of the persistent 16x16x32 conv
 ])
 def test_conv3d(eng, cin, cout, k, dims):
@@ -43,6 +43,27 @@ def test_conv3d(eng, cin, cout, k, dims):
     b = _rand((cout,), 3) * 0.1
     ref = F.conv3d(x, w, b, padding=k // 2)
     got = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), k)
+    assert rel_err(got, ref) < RTOL
+
+
+@pytest.mark.parametrize("cin,cmid,cout,dims,batch", [
+    (128, 64, 64, (8, 8, 8), 2),            # W = 8: 32 x rows per workgroup tile, operand emitted by the 1x1 kernel
+    (256, 128, 32, (4, 8, 16), 2),          # two 64-channel epilogue passes
+    (512, 256, 64, (3, 5, 64), 1),          # W = 64 (the production width), ragged last tile (960 voxels), four passes
+    (16, 64, 32, (5, 6, 32), 2),            # a single chunk: the second chunk of the pair is missing; W = 32, ragged last tile
+    (64, 64, 64, (6, 5, 9), 2),             # W = 9 does not divide the tile: raw output + operand pass
+    (32, 128, 64, (2, 3, 66), 1),           # W > 64: raw output + operand pass
+])
+def test_fused_norm_conv1x1_into_winograd_conv(eng, cin, cmid, cout, dims, batch):
+    """kernels_conv1x1.hip: InstanceNorm + ReLU applied on load of a RAW source, split-f16 MFMA GEMM, and the Winograd operand
+    of the following 3x3x3 conv written by the epilogue - against torch's conv3d(conv3d(relu(instance_norm(x))))."""
+    x = _rand((batch, cin, *dims), 21) * 2.0 + 0.5
+    w1 = _rand((cmid, cin, 1, 1, 1), 22) * (3.0 / cin) ** 0.5
+    b1 = _rand((cmid,), 23) * 0.1
+    w3 = _rand((cout, cmid, 3, 3, 3), 24) * (3.0 / (cmid * 27)) ** 0.5
+    b3 = _rand((cout,), 25) * 0.1
+    ref = F.conv3d(F.conv3d(F.relu(F.instance_norm(x, eps=1e-5)), w1, b1), w3, b3, padding=1)
+    got = eng.op_norm_conv1_conv3(x.cuda(), w1.numpy().reshape(cmid, cin), b1.numpy(), w3.numpy(), b3.numpy())
     assert rel_err(got, ref) < RTOL
 
 

@@ -403,3 +403,86 @@ def test_threshold_points_full_size_volume(eng):
     idx = eng.threshold_points(v, 0.999)
     assert idx.numel() == int((v > 0.999).sum().item()) and idx.numel() > 100000
     assert bool((idx[1:] > idx[:-1]).all()) and bool((v.view(-1)[idx] > 0.999).all())
+
+
+def _blobs(shape, centres, rng, sigma=1.6):
+    """A CA-like probability volume: Gaussian blobs at `centres` (float positions) plus a little noise."""
+    g = np.indices(shape, dtype=np.float32)
+    v = np.zeros(shape, np.float32)
+    for c in centres:
+        v += np.exp(-((g[0] - c[0]) ** 2 + (g[1] - c[1]) ** 2 + (g[2] - c[2]) ** 2) / (2 * sigma ** 2)).astype(np.float32)
+    return np.clip(v * 0.9 + rng.random(shape, dtype=np.float32) * 0.05, 0, 1).astype(np.float32)
+
+
+def _chain(n, start, rng):
+    """A CA-trace-like chain: consecutive points 3.8 apart in random directions."""
+    pts = [np.array(start, float)]
+    while len(pts) < n:
+        d = rng.normal(size=3)
+        pts.append(pts[-1] + 3.8 * d / np.linalg.norm(d))
+    return np.array(pts)
+
+
+def test_cluster_scores_nms_and_neighbour_matrix_bit_exact(eng):
+    """The rest of Solver.clustering (modeler.py:775-797 cluster scores, :799-831 sorted greedy NMS, :860-888 distance /
+    neighbour / backbone-density matrix) against the reference's own numpy statements (oracle/cluster_oracle.py).  DBSCAN
+    (open3d) is replaced by connected components of a coarse grid here: any integer labelling exercises the same code."""
+    from mica_amd import clustering as cl
+    from oracle import cluster_oracle as co
+    rng = np.random.default_rng(123)
+    shape = (72, 64, 80)
+    chains = [np.clip(_chain(22, (20, 20, 20), rng), 4, 58), np.clip(_chain(15, (50, 40, 60), rng), 4, 58),
+              np.clip(_chain(8, (12, 50, 70), rng), 4, 58), np.clip(_chain(1, (60, 8, 8), rng), 4, 58)]
+    centres = np.concatenate(chains)
+    ca = _blobs(shape, centres, rng)
+    strong = np.concatenate(chains[:2])             # backbone density along the first two chains only: the third cluster scores
+    bb = _blobs(shape, np.concatenate([strong, (strong[1:] + strong[:-1]) / 2]), rng, sigma=2.0)      # low, the fourth is tiny
+    bb += 0.35 * _blobs(shape, chains[2], rng, sigma=2.0)
+    aa = rng.random((20, *shape), dtype=np.float32)
+    aa /= aa.sum(0, keepdims=True)
+    vols = {"carbon_alpha_probability": torch.from_numpy(ca).cuda(), "backbone_probability": torch.from_numpy(bb).cuda(),
+            "amino_acid_probability": torch.from_numpy(aa).cuda()}
+    thr, radius = 0.3, 9
+    pts, cav, bbv = cl.candidate_points(eng, vols, thr)
+    assert np.array_equal(pts, co.threshold_points(ca, thr)) and 2000 < len(pts) < 60000
+    # labels: nearest chain by coarse position (three clusters of very different size and score), a few noise points
+    dist = np.stack([np.min(np.linalg.norm(pts[:, None, :] - c[None], axis=2), axis=1) for c in chains])
+    labels = np.argmin(dist, axis=0).astype(np.int64)
+    labels[np.min(dist, axis=0) > 4.0] = -1
+    labels[::97] = -1
+    ref_sum, ref_avg, ref_val = co.cluster_scores(bb, pts, labels)
+    got_sum, got_avg, got_val = cl.cluster_scores(eng, bbv, labels)
+    assert [float(v) for v in got_sum] == [float(v) for v in ref_sum], (got_sum, ref_sum)
+    assert [float(v) for v in got_avg] == [float(v) for v in ref_avg]
+    assert np.array_equal(got_val, ref_val) and 0 < ref_val.sum() < len(pts)
+    assert len(ref_sum) == 4 and ref_avg[3] == 0 and 0 < ref_avg[2] < max(ref_avg) / 2      # every branch of :783-796
+    # long segments: numpy's piecewise pairwise order (8192-element pieces) on 1 .. 300k values
+    lens = [1, 7, 8, 9, 127, 128, 129, 1000, 8191, 8192, 8193, 20000, 100001, 300007]
+    vals = (rng.random(sum(lens), dtype=np.float32) ** 2).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    sums = eng.segment_sums(torch.from_numpy(vals).cuda(), torch.from_numpy(off).cuda()).cpu().numpy()
+    assert np.array_equal(sums, np.array([np.sum(vals[off[i]:off[i + 1]]) for i in range(len(lens))], dtype=np.float32))
+
+    # NMS on the valid clusters
+    pred = co.sorted_pred_list(ca, pts, ref_val)
+    ref_cands = np.array(co.nms(pred.copy(), thr, radius))
+    got_cands = cl.nms(eng, cav, pts, got_val, shape, thr, radius)
+    assert got_cands.shape == ref_cands.shape and np.array_equal(got_cands, ref_cands) and 10 < len(ref_cands) < 400
+    # a non-integer radius and a threshold that cuts the sorted list
+    ref2 = np.array(co.nms(pred.copy(), 0.6, 5.5))
+    got2 = cl.nms(eng, cav, pts, got_val, shape, 0.6, 5.5)
+    assert np.array_equal(got2, ref2) and len(ref2) > len(ref_cands) // 4
+
+    # refinement, then distances / neighbour lists / neighbour matrix on the refined positions
+    new_c, new_a, kept = cl.refine(eng, vols, got_cands)
+    rc, ra, rk = co.refine_candidates(ca, aa, ref_cands)
+    assert np.array_equal(new_c, rc) and np.array_equal(new_a, ra) and np.array_equal(kept, rk)
+    rdis, rlists, rmat = co.neighbour_matrix(rc, bb)
+    gdis, glists, gmat = cl.neighbours(eng, vols, new_c)
+    assert gdis.dtype == np.float64 and np.array_equal(gdis, rdis)
+    for gl, rl in zip(glists, rlists):
+        assert len(gl) == len(rl) and all(np.array_equal(a, b) for a, b in zip(gl, rl))
+    assert np.array_equal(gmat, rmat) and (rmat > 0).sum() > len(rc)
+    # both promotion branches of the last sum occur: distance term zero (3.3 <= dis <= 4.3) and non-zero
+    inband = (rdis >= 2) & (rdis <= 6)
+    assert ((np.abs(rdis - 3.8) <= 0.5) & inband).any() and ((np.abs(rdis - 3.8) > 0.5) & inband).any()
