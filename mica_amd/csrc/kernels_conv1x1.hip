@@ -17,8 +17,11 @@
 // v_mfma_f32_16x16x32_f16: per PAIR of 16-channel chunks (c, c') three instructions per 16x16 tile,
 //   X(c)  : A = [a_hi(c) | a_lo(c)]   B = [b_hi(c) ; b_hi(c)]          X(c') likewise
 //   Y     : A = [a_hi(c) | a_hi(c')]  B = [b_lo(c) ; b_lo(c')]
-// Workgroup: 8 waves, 256 voxels x Cout; wave (wm, wn) owns 128 voxels (8 row fragments) x the column tiles {wn + 4 j}.
-// LDS: two 32-KB stages of [chunk-in-pair 2][plane 4 = hi/lo x channel half][256 rows] 16-byte slots (a ds_read_b128 lane
+// Workgroup: 4 waves, 128 voxels x Cout; wave wn owns all 128 voxels (8 row fragments) x the column tiles {wn + 4 j}.  Small
+// workgroups on purpose: two to three of them share a CU (43 KB of LDS each), out of phase, so that one's loads overlap another's
+// MFMAs and a third's epilogue stores - with one 8-wave workgroup per CU the kernel alternated between a read phase and a
+// write phase and reached 2.7 TB/s.
+// LDS: two 16-KB stages of [chunk-in-pair 2][plane 4 = hi/lo x channel half][128 rows] 16-byte slots (a ds_read_b128 lane
 // group covers 16 consecutive slots), refilled one pair ahead: global loads for pair p+1 are issued before the MFMAs of
 // pair p and committed to LDS after them, one barrier per pair.
 #include "common.h"
@@ -27,7 +30,8 @@ namespace mica {
 
 typedef float floatx4c __attribute__((ext_vector_type(4)));
 
-constexpr int C1_ROWS = 256;
+constexpr int C1_ROWS = 128;
+constexpr int C1_NT = 256;                              // threads per workgroup
 constexpr int C1_STAGE = 2 * 4 * C1_ROWS * 16;          // bytes per stage
 constexpr int C1_TS = 68;                               // floats per row of the epilogue staging tile (64 + pad)
 constexpr int C1_TBYTES = C1_ROWS * C1_TS * 4;
@@ -49,14 +53,14 @@ __device__ __forceinline__ void c1_split8(const float (&y)[8], half8& hi, half8&
 }
 
 template <int NCT, bool WINO>
-__global__ __launch_bounds__(512) void conv1x1_kernel(Conv1Srcs src, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
+__global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x1_kernel(Conv1Srcs src, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
                                                       const float* __restrict__ bias, float out_scale, float* __restrict__ out_raw,
                                                       SplitView wino, Dims d, int cout, int total_chunks, SplitEnc enc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* tab = reinterpret_cast<float2*>(smem + C1_LDS - C1_TAB);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wn = wave;
     const int b = blockIdx.y;
     const int V = d.D * d.H * d.W;
     const int v0 = blockIdx.x * C1_ROWS;
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(Conv1Srcs src, const _Floa
         const Conv1Src& s = src.s[si];
         if (s.kind == 1) {
             const int Cs = s.chunks_total * 16;
-            for (int ch = tid; ch < Cs; ch += 512)
+            for (int ch = tid; ch < Cs; ch += C1_NT)
                 tab[si * 512 + ch] = s.mean ? make_float2(s.mean[(int64_t)b * Cs + ch], s.rstd[(int64_t)b * Cs + ch]) : make_float2(0.f, 1.f);
         }
     }
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(Conv1Srcs src, const _Floa
             } else {                                          // split: two 16-byte pieces, piece = (row, plane)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const int id = tid + 512 * k, plane = id & 3, row = id >> 2;
+                    const int id = tid + C1_NT * k, plane = id & 3, row = id >> 2;
                     const int v = v0 + row;
                     if (v < V)
                         st[cc][k] = *reinterpret_cast<const float4*>(reinterpret_cast<const _Float16*>(s.p) +
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(Conv1Srcs src, const _Floa
             } else {                                          // split source, or the missing second chunk of an odd count (zeros)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const int id = tid + 512 * k, plane = id & 3, row = id >> 2;
+                    const int id = tid + C1_NT * k, plane = id & 3, row = id >> 2;
                     *reinterpret_cast<float4*>(cb + (plane * C1_ROWS + row) * 16) = st[cc][k];
                 }
             }
@@ -152,27 +156,39 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(Conv1Srcs src, const _Floa
 
     const int npairs = (total_chunks + 1) >> 1;
     const _Float16* wb = wpk + (int64_t)b * wpk_bstride;
-    const int rowbase = wm * 128 + lr;
+    const int rowbase = lr;
+
+    // weight fragments of (pair, kind): kind 0 = X(c), 1 = X(c'), 2 = Y.  They come straight from L1/L2 and are fetched one kind
+    // ahead (two register sets), so that their latency hides behind the previous kind's MFMAs
+    auto bload = [&](int pair, int kind, half8 (&bq)[NCT]) {
+        const int c0 = 2 * pair, c1 = (2 * pair + 1 < total_chunks) ? 2 * pair + 1 : 2 * pair;
+        const int gc = kind == 0 ? c0 : kind == 1 ? c1 : ((lg >> 1) ? c1 : c0);
+        const int q = (kind == 2 ? 2 : 0) + (lg & 1);
+        const _Float16* wp = wb + ((int64_t)(gc * 4 + q) * cout + wn * 16 + lr) * 8;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) bq[c] = *reinterpret_cast<const half8*>(wp + (int64_t)c * 64 * 8);
+    };
+    half8 bq[2][NCT];
 
     __syncthreads();                                  // norm table ready
     fetch(0);
     commit(0, smem);
+    bload(0, 0, bq[0]);
     for (int p = 0; p < npairs; ++p) {
         char* cur = smem + (p & 1) * C1_STAGE;
+        const bool has2 = 2 * p + 1 < total_chunks;   // the pair's second chunk exists (always, but for the last pair of an odd count)
         if (p + 1 < npairs) fetch(p + 1);
         __syncthreads();                              // stage p is complete; nobody still reads the stage that commit(p+1) will overwrite
-        const int c0 = 2 * p, c1 = (2 * p + 1 < total_chunks) ? 2 * p + 1 : 2 * p;
+        // three steps per pair: X(c), X(c'), Y - or X(c), Y, (nothing) when the second chunk is missing; the fragments of the next
+        // step are requested before this step's MFMAs (two register sets, set = step & 1; a pair's first step uses set 0, so after
+        // three steps the next pair's first fragments are moved from set 1 to set 0)
 #pragma unroll
-        for (int kind = 0; kind < 3; ++kind) {        // 0: X(c), 1: X(c'), 2: Y
-            if (kind == 1 && 2 * p + 1 >= total_chunks) continue;
-            half8 bq[NCT];
-            {
-                const int gc = kind == 0 ? c0 : kind == 1 ? c1 : ((lg >> 1) ? c1 : c0);
-                const int q = (kind == 2 ? 2 : 0) + (lg & 1);
-                const _Float16* wp = wb + ((int64_t)(gc * 4 + q) * cout + wn * 16 + lr) * 8;
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) bq[c] = *reinterpret_cast<const half8*>(wp + (int64_t)c * 64 * 8);
-            }
+        for (int stp = 0; stp < 3; ++stp) {
+            const int kind = has2 ? stp : (stp == 0 ? 0 : 2);
+            if (!has2 && stp == 2) break;
+            // request the next step's fragments
+            if (stp + 1 < (has2 ? 3 : 2)) bload(p, has2 ? stp + 1 : 2, bq[(stp + 1) & 1]);
+            else if (p + 1 < npairs) bload(p + 1, 0, bq[(stp + 1) & 1]);
             // A: X(cc) reads plane lg of chunk cc; Y reads the hi plane (lg & 1) of chunk (lg >> 1)
             const int aplane = kind == 0 ? lg : kind == 1 ? 4 + lg : (lg >> 1) * 4 + (lg & 1);
             const char* ap = cur + (aplane * C1_ROWS + rowbase) * 16;
@@ -180,14 +196,22 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(Conv1Srcs src, const _Floa
             for (int f = 0; f < 8; ++f) {
                 const half8 a = *reinterpret_cast<const half8*>(ap + f * 16 * 16);
 #pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[c], acc[f][c], 0, 0, 0);
+                for (int c = 0; c < NCT; ++c) acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[stp & 1][c], acc[f][c], 0, 0, 0);
+                if (f & 1) __builtin_amdgcn_sched_barrier(0);     // keeps the LDS reads from being hoisted over the whole step (registers)
             }
         }
-        if (p + 1 < npairs) commit(p + 1, smem + ((p + 1) & 1) * C1_STAGE);
+        if (p + 1 < npairs) {
+            const int last = has2 ? 3 : 2;            // the next pair's first fragments sit in set last & 1
+            if (last & 1) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) bq[0][c] = bq[1][c];
+            }
+            commit(p + 1, smem + ((p + 1) & 1) * C1_STAGE);
+        }
     }
     if (bad) atomicOr(enc.err, bad);
 
-    // ---- epilogue: 64 output channels per pass through the staging tile T[256][64 (+4)] ----
+    // ---- epilogue: 64 output channels per pass through the staging tile T[128][64 (+4)] ----
     float* T = reinterpret_cast<float*>(smem);
     const int Wh = (d.W + 1) >> 1, Vh = d.D * d.H * Wh;
     int bad2 = 0;
@@ -201,13 +225,13 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(Conv1Srcs src, const _Floa
             for (int f = 0; f < 8; ++f)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)           // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + i
-                    T[(wm * 128 + f * 16 + lg * 4 + i) * C1_TS + wn * 16 + lr] = acc[f][pass][i] * out_scale + bv;
+                    T[(f * 16 + lg * 4 + i) * C1_TS + wn * 16 + lr] = acc[f][pass][i] * out_scale + bv;
         }
         __syncthreads();
         if (!WINO) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int id = it * 512 + tid, cg = id & 15, row = id >> 4;
+                const int id = it * C1_NT + tid, cg = id & 15, row = id >> 4;
                 const int v = v0 + row;
                 if (v < V)
                     *reinterpret_cast<float4*>(out_raw + ((int64_t)b * V + v) * cout + pass * 64 + cg * 4) =
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(512) void conv1x1_kernel(Conv1Srcs src, const _Floa
             // d_k = y(2i-1+k), zero outside the row:  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                const int id = it * 512 + tid, phl = id & 127, kg = id >> 7;
+                const int id = it * C1_NT + tid, phl = id & 63, kg = id >> 6;
                 const int yr = phl / Wh, i = phl - yr * Wh;
                 const int vrow = v0 + yr * d.W;       // first voxel of this x row
                 if (vrow < V) {
@@ -270,7 +294,7 @@ static void launch_conv1x1_t(const Conv1Srcs& src, const _Float16* wpk, int64_t 
     }
     const int V = d.D * d.H * d.W;
     dim3 grid((V + C1_ROWS - 1) / C1_ROWS, B);
-    hipLaunchKernelGGL((conv1x1_kernel<NCT, WINO>), grid, dim3(512), C1_LDS, st, src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, d, cout,
+    hipLaunchKernelGGL((conv1x1_kernel<NCT, WINO>), grid, dim3(C1_NT), C1_LDS, st, src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, d, cout,
                        total, enc);
 }
 

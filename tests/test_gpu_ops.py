@@ -152,3 +152,30 @@ def test_postprocess(eng):
     assert float((gc.cpu() - rc).abs().max()) < 1e-6
     assert float((ga.cpu() - ra).abs().max()) < 1e-6
     assert torch.equal(gp.cpu().long(), rp)
+    # the prediction is the first maximum of the softmax SCORES (predict.py:349): logits so close that their scores round to the
+    # same float resolve to the lower class, like torch.max on the scores
+    aa2 = torch.full((1, 21, 16, 16, 16), -30.0)
+    aa2[:, 5] = 0.001
+    aa2[:, 9] = torch.nextafter(torch.tensor(0.001), torch.tensor(1.0))      # a larger logit (one ulp), an equal score after rounding
+    aa2[:, 1] = -1.0
+    _, _, ra2, rp2 = mo.postprocess(bb[:1], ca[:1], aa2)
+    _, _, ga2, gp2 = eng.postprocess(bb[:1].cuda(), ca[:1].cuda(), aa2.cuda())
+    assert float(aa2[0, 9, 0, 0, 0]) > float(aa2[0, 5, 0, 0, 0]) and int(rp2.flatten()[0]) == 4      # class 5 -> index 4 of the 20 scores
+    assert torch.equal(gp2.cpu().long(), rp2)
+
+
+def test_forward_records_equal_forward_tiles(weights):
+    """mica_forward_records writes the record layout [T,23,S^3] (bb, ca, aa_pred, aa_prob x20) that stitch_tiles and the
+    multi-GPU exchange use: bit-identical to the four tensors of mica_forward_tiles."""
+    from mica_amd.engine import AF_PER_TILE, Engine
+    S = 16
+    e = Engine(0, max_batch=2, tile_size=S)
+    e.load_state_dict(weights)
+    x = _rand((3, S, S, S), 31, 0.0, 1.0).cuda()
+    af = (_rand((3, 24, S, S, S), 32, 0.0, 1.0) < 0.01).float().cuda()
+    af[1] = 0
+    bbp, cap, aap, pred = e.forward_tiles(x, af, af_mode=AF_PER_TILE)
+    rec = torch.empty((3, 23, S, S, S), device="cuda")
+    e.forward_records(x, af, rec, af_mode=AF_PER_TILE)
+    assert torch.equal(rec[:, 0], bbp) and torch.equal(rec[:, 1], cap) and torch.equal(rec[:, 2], pred) and torch.equal(rec[:, 3:], aap)
+    e.close()
