@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
-T=${1:-r02final}
+T=${1:-full}
 mkdir -p gpurun_out/$T
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/$T/t_all.log 2>&1; rc=$?; echo "all gpu tests rc=$rc"; tail -3 gpurun_out/$T/t_all.log
 [ $rc -eq 0 ] || exit $rc
