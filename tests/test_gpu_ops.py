@@ -53,6 +53,7 @@ def test_conv3d(eng, cin, cout, k, dims):
     (16, 64, 32, (5, 6, 32), 2),            # a single chunk: the second chunk of the pair is missing; W = 32, ragged last tile
     (64, 64, 64, (6, 5, 9), 2),             # W = 9 does not divide the tile: raw output + operand pass
     (32, 128, 64, (2, 3, 66), 1),           # W > 64: raw output + operand pass
+    (64, 64, 32, (2, 2, 4), 3),             # a volume smaller than one workgroup tile (16 voxels), W = 4
 ])
 def test_fused_norm_conv1x1_into_winograd_conv(eng, cin, cmid, cout, dims, batch):
     """kernels_conv1x1.hip: InstanceNorm + ReLU applied on load of a RAW source, split-f16 MFMA GEMM, and the Winograd operand
