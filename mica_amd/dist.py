@@ -61,14 +61,13 @@ class RecordExchange:
     def _gather(self, slot):
         if self.world == 1:
             return None
-        if self.backend == "nccl":
-            return dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
-        if self.device.type == "cuda":                  # gloo rehearsal on a GPU: through the host
-            parts = [torch.empty(self.send[slot].shape, dtype=self.send[slot].dtype) for _ in range(self.world)]
-            dist.all_gather(parts, self.send[slot].cpu(), group=self.group)
-            self.recv[slot].copy_(torch.cat(parts))
+        if self.backend == "gloo" and self.device.type == "cuda":      # rehearsal of N > 1 on a GPU without RCCL: through the host
+            host = torch.empty(self.recv[slot].shape, dtype=self.recv[slot].dtype)
+            dist.all_gather_into_tensor(host, self.send[slot].cpu(), group=self.group)
+            self.recv[slot].copy_(host)
             return None
-        return dist.all_gather(list(self.recv[slot].chunk(self.world)), self.send[slot], group=self.group, async_op=True)
+        # the same call with RCCL (device tensors, asynchronous on the collective's stream) and in the CPU tests (gloo)
+        return dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
 
     def _finish(self):
         work, slot, layout = self.pending

@@ -124,6 +124,37 @@ def test_sharded_records_gloo_world2(tmp_path, T, B):
         assert torch.equal(got[f], single[f])
 
 
+def _bench_worker(rank, world, port, out_path):
+    """bench.py's N > 1 step loop in miniature: RecordExchange.post per step with a wrapping tile layout."""
+    from mica_amd.dist import RecordExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, nb, got = 2, 3, []                                     # 3 whole batches per "map": step k of rank r takes batch (k*world + r) % nb
+    first_of = lambda k, r: ((k * world + r) % nb) * B
+    ex = RecordExchange(B, (2, 4, 4, 4), torch.device("cpu"), lambda rec, first: got.append((first, rec.clone())), stitch_rank=0)
+    for k in range(5):
+        ex.post(k, _producer(first_of(k, rank), B) + 100.0 * k, [(first_of(k, r), B) for r in range(world)])
+        assert len(got) == (2 * k if rank == 0 else 0)        # step k-1 is stitched while step k is in flight
+    ex.flush()
+    if rank == 0:
+        torch.save(got, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_record_exchange_step_loop_gloo_world2(tmp_path):
+    port = 29500 + (os.getpid() + 77) % 2000
+    out = str(tmp_path / "steps.pt")
+    mp.spawn(_bench_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    assert len(got) == 10
+    for i, (first, rec) in enumerate(got):
+        k, r = divmod(i, 2)                                   # stitched in step order, rank order within a step
+        assert first == ((k * 2 + r) % 3) * 2
+        assert torch.equal(rec, _producer(first, 2) + 100.0 * k)
+
+
 def _pdb_line(rec, serial, name, altloc, resname, chain, resseq, x, y, z, occ=1.0):
     nm = name if len(name) == 4 else " " + name.ljust(3)
     return "%-6s%5d %4s%1s%3s %1s%4d    %8.3f%8.3f%8.3f%6.2f%6.2f          %2s\n" % (
