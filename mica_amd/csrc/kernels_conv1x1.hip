@@ -25,6 +25,8 @@
 // group covers 16 consecutive slots), refilled one pair ahead: global loads for pair p+1 are issued before the MFMAs of
 // pair p and committed to LDS after them, one barrier per pair.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace mica {
 
@@ -302,7 +304,12 @@ static void launch_conv1x1_t(const Conv1Srcs& src, const _Float16* wpk, int64_t 
 void launch_conv1x1(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out_raw,
                     SplitView wino, int B, Dims d, int cout, SplitEnc enc, hipStream_t st) {
     int total = 0;
-    for (int i = 0; i < src.n; ++i) total += src.s[i].chunks;
+    for (int i = 0; i < src.n; ++i) {
+        total += src.s[i].chunks;
+        // the norm table in LDS holds 512 channels per raw source (the widest tensor of the network); shapes are fixed by the
+        // forward graph and checked by the single-op entry points
+        if (src.s[i].kind == 1 && src.s[i].chunks_total * 16 > 512) { fprintf(stderr, "conv1x1: raw source wider than 512 channels\n"); abort(); }
+    }
     const bool w = wino.p != nullptr;
 #define C1_GO(NCT)                                                                                                          \
     do {                                                                                                                    \

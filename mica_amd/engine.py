@@ -77,6 +77,12 @@ class Engine:
         self.weights_loaded = True
 
     # -- forward ----------------------------------------------------------------------------------
+    def _check_batch_mode(self, n: int, af, af_mode: int):
+        """The batch-wide AF3 test (models/model.py:60) is a property of ONE forward call: a batch larger than the engine's
+        max_batch would be cut into several calls and silently become a different test."""
+        if af is not None and af_mode == AF_BATCH and n > self.max_batch:
+            raise MicaHipError(f"AF_BATCH over {n} tiles needs an engine with max_batch >= {n} (this one: {self.max_batch})")
+
     def forward_logits(self, exp_map: torch.Tensor, af: torch.Tensor | None, af_mode: int = AF_BATCH):
         S = self.tile_size
         exp_map = _f32c(exp_map, "exp_map")
@@ -87,6 +93,7 @@ class Engine:
             af = _f32c(af, "af_features")
             if tuple(af.shape) != (B, 24, S, S, S):
                 raise MicaHipError(f"af_features must be [B,24,{S},{S},{S}], got {tuple(af.shape)}")
+        self._check_batch_mode(B, af, af_mode)
         bb = torch.empty((B, 4, S, S, S), dtype=torch.float32, device=self.device)
         ca = torch.empty_like(bb)
         aa = torch.empty((B, 21, S, S, S), dtype=torch.float32, device=self.device)
@@ -105,6 +112,7 @@ class Engine:
         map_tiles = _f32c(map_tiles, "map_tiles").view(T, 1, S, S, S)
         if af_tiles is not None:
             af_tiles = _f32c(af_tiles, "af_tiles").view(T, 24, S, S, S)
+        self._check_batch_mode(T, af_tiles, af_mode)
         if out is None:
             out = (torch.empty((T, S, S, S), dtype=torch.float32, device=self.device),
                    torch.empty((T, S, S, S), dtype=torch.float32, device=self.device),
@@ -127,6 +135,7 @@ class Engine:
         map_tiles = _f32c(map_tiles, "map_tiles").view(T, 1, S, S, S)
         if af_tiles is not None:
             af_tiles = _f32c(af_tiles, "af_tiles").view(T, 24, S, S, S)
+        self._check_batch_mode(T, af_tiles, af_mode)
         if rec.dtype != torch.float32 or not rec.is_cuda or not rec.is_contiguous() or tuple(rec.shape) != (T, 23, S, S, S):
             raise MicaHipError(f"rec must be a contiguous float32 CUDA(HIP) tensor [{T},23,{S},{S},{S}]")
         for b0 in range(0, T, self.max_batch):
