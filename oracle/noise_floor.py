@@ -11,7 +11,12 @@ tests/golden/manifest.json["noise_floor"] with the same two metrics the GPU test
   scaled   max |a-b| / max(|b|, rms(b))                       (tests/test_gpu_model.py::scaled_err)
   frac_rel fraction of voxels with |a-b| / |b| > 1e-4          (true per-voxel relative error)
 
-TEST INFRASTRUCTURE - documentation of the tolerance, nothing in the product or the tests depends on running it.
+With --truth it also runs the reference module in float64 (`MICA().double()`) on the S = 16 inputs: the exact result up to
+~1e-15, against which both the reference's own float32 path and the GPU path can be measured.  The float64 logits are
+committed as tests/golden/truth64_S16_<weights>.npz and the float32 reference's distance from them is recorded in the manifest;
+tests/test_gpu_model.py asserts that the GPU path is not further from the truth than the reference's float32 path is.
+
+TEST INFRASTRUCTURE - documentation of the tolerance; only the --truth fixtures are read by a test.
 """
 from __future__ import annotations
 
@@ -51,7 +56,7 @@ def main():
     from models.model import MICA
     out = {"torch": torch.__version__, "cases": {}}
     sets = {"w2022g6": (2022, 6.0), "w7g3": (7, 3.0), "w99g10": (99, 10.0)}
-    sizes = [16] + ([64] if "--s64" in sys.argv else [])
+    sizes = ([] if "--truth-only" in sys.argv else [16]) + ([64] if "--s64" in sys.argv else [])
     for S in sizes:
         for tag, (seed, gain) in sets.items():
             if S == 64 and tag != "w2022g6":
@@ -74,6 +79,31 @@ def main():
             print(S, tag, json.dumps(rec), flush=True)
     mp = os.path.join(ROOT, "tests", "golden", "manifest.json")
     manifest = json.load(open(mp))
+    if "--truth" in sys.argv:
+        S = 16
+        truth = {}
+        for tag, (seed, gain) in sets.items():
+            sd = {k: torch.from_numpy(v.copy()) for k, v in synth_state_dict(seed, gain).items()}
+            m = MICA()
+            m.load_state_dict(sd, strict=True)
+            m.eval()
+            x = torch.from_numpy(synth_density((1, 1, S, S, S), 12))
+            af = torch.from_numpy(synth_af((S, S, S), 12, 0.01))[None]
+            r32 = run(m, x, af, 8)
+            m64 = MICA().double()
+            m64.load_state_dict({k: v.double() for k, v in sd.items()}, strict=True)
+            m64.eval()
+            with torch.no_grad():
+                t64 = [t.numpy().copy() for t in m64(x.double(), af.double())]
+            truth[tag] = {n: metrics(a, b) for n, a, b in zip(("bb", "ca", "aa"), r32, t64)}
+            np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"truth64_S16_{tag}.npz"), bb=t64[0], ca=t64[1], aa=t64[2], seed=12, afp=0.01,
+                                S=S, wseed=seed, wgain=gain,
+                                ref32_scaled=np.array([truth[tag][n]["scaled"] for n in ("bb", "ca", "aa")]))
+            print("truth64", tag, json.dumps(truth[tag]), flush=True)
+        manifest["reference_float32_vs_float64_truth_S16"] = truth
+    if "--truth-only" in sys.argv:
+        json.dump(manifest, open(mp, "w"), indent=1)
+        return
     manifest["noise_floor"] = out
     json.dump(manifest, open(mp, "w"), indent=1)
 
