@@ -167,6 +167,13 @@ int mica_op_instnorm_relu(mica_ctx* ctx, const float* d_x, int batch, int c, int
 /* Depthwise Conv3d(C,C,3,padding=1,groups=C) on NCDHW (model.py:80). */
 int mica_op_depthwise3(mica_ctx* ctx, const float* d_x, int batch, int c, int d, int h, int w,
                        const float* h_w, const float* h_b, float* d_y, void* stream);
+/* relu(InstanceNorm3d(dwconv3(SE(relu(InstanceNorm3d(x)))))) on NCDHW: the local branch of DualAttention behind the SE block
+ * (model.py:254-258, 80-82, 99) the way the forward graph runs it - normalisation applied on load, the SE block's global
+ * average pool summed by the depthwise kernel, the SE gate folded into the output's InstanceNorm constants.
+ * h_dw_w f32[C][27], h_dw_b f32[C]; SE weights as torch's Linear: h_fc0_w f32[C/16][C], h_fc0_b, h_fc3_w f32[C][C/16], h_fc3_b. */
+int mica_op_se_depthwise(mica_ctx* ctx, const float* d_x, int batch, int c, int d, int h, int w, const float* h_dw_w,
+                         const float* h_dw_b, const float* h_fc0_w, const float* h_fc0_b, const float* h_fc3_w,
+                         const float* h_fc3_b, float* d_y, void* stream);
 /* The four Cin=1 stem convs k=3,5,7,9 -> 128 channels (model.py:9-14,49-51), NCDHW out.
  * Uses the ctx's loaded input_processing.exp_convs.* weights.                                 */
 int mica_op_stem(mica_ctx* ctx, const float* d_map, int batch, int d, int h, int w, float* d_y, void* stream);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mica_op_norm_conv1_conv3": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _FP, _FP, _I, _P, _P]),
     "mica_op_instnorm_relu": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mica_op_depthwise3": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _P, _P]),
+    "mica_op_se_depthwise": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _FP, _FP, _FP, _FP, _P, _P]),
     "mica_op_stem": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "mica_get_activation_scale": (_F, [_P]),
     "mica_set_activation_scale": (_I, [_P, _F]),

@@ -3,6 +3,7 @@
 #include "../../include/mica_hip.h"
 #include "common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1046,6 +1047,56 @@ int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, 
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
     launch_depthwise(a, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, nullptr, nullptr, st);
     launch_nhwc_to_nchw(b, batch, ch, V, d_y, st);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(st));
+    return MICA_OK;
+}
+
+int mica_op_se_depthwise(mica_ctx* c, const float* d_x, int batch, int ch, int d, int h, int w, const float* h_dw_w, const float* h_dw_b,
+                         const float* h_fc0_w, const float* h_fc0_b, const float* h_fc3_w, const float* h_fc3_b, float* d_y, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_x || !d_y || !h_dw_w || !h_dw_b || !h_fc0_w || !h_fc0_b || !h_fc3_w || !h_fc3_b || batch < 1 || ch < 32 || ch > 256 || !pow2_8_512(ch) ||
+        d < 1 || h < 1 || w < 1) {
+        c->err = "mica_op_se_depthwise: bad argument (C a power of two in [32, 256])";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const Dims dm{d, h, w};
+    const int V = d * h * w, Ch = ch / 16;
+    const int nblk = ((w + 15) / 16) * ((h + 7) / 8);                 // upper bound of the depthwise kernel's blocks per channel slab
+    Tmp t;
+    float* a = t.get<float>((int64_t)batch * V * ch);
+    float* u = t.get<float>((int64_t)batch * V * ch);
+    float* y = t.get<float>((int64_t)batch * V * ch);
+    float* dw = t.get<float>(27 * ch);
+    float* db = t.get<float>(ch);
+    float *w1 = t.get<float>((int64_t)Ch * ch), *b1 = t.get<float>(Ch), *w2 = t.get<float>((int64_t)ch * Ch), *b2 = t.get<float>(ch);
+    float *m0 = t.get<float>((int64_t)batch * ch), *r0 = t.get<float>((int64_t)batch * ch), *m1 = t.get<float>((int64_t)batch * ch), *r1 = t.get<float>((int64_t)batch * ch);
+    float *pool = t.get<float>((int64_t)batch * ch), *gse = t.get<float>((int64_t)batch * ch);
+    const int64_t wsn = std::max(stats_ws_floats(batch, ch), (int64_t)batch * nblk * ch * 3);
+    float* ws = t.get<float>(wsn);
+    float* wsg = t.get<float>((int64_t)batch * nblk * ch);
+    int* derr = t.get<int>(1);
+    if (!a || !u || !y || !dw || !db || !w1 || !b1 || !w2 || !b2 || !m0 || !r0 || !m1 || !r1 || !pool || !gse || !ws || !wsg || !derr) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
+    std::vector<float> wt((size_t)27 * ch);
+    for (int cc = 0; cc < ch; ++cc)
+        for (int tp = 0; tp < 27; ++tp) wt[(size_t)tp * ch + cc] = h_dw_w[(size_t)cc * 27 + tp];
+    HIPC(c, hipMemcpy(dw, wt.data(), sizeof(float) * 27 * ch, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(db, h_dw_b, sizeof(float) * ch, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(w1, h_fc0_w, sizeof(float) * Ch * ch, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(b1, h_fc0_b, sizeof(float) * Ch, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(w2, h_fc3_w, sizeof(float) * ch * Ch, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(b2, h_fc3_b, sizeof(float) * ch, hipMemcpyHostToDevice));
+    HIPC(c, hipMemsetAsync(derr, 0, 4, st));
+    launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
+    launch_stats(a, batch, V, ch, 1e-5f, m0, r0, ws, st);                                  // x3 = relu(IN(x)) is applied on load
+    const int P = launch_depthwise(a, batch, dm, ch, m0, r0, nullptr, dw, db, u, ws, wsg, st);
+    launch_finalize_sum(wsg, batch, P, ch, 1.0f / (float)V, pool, st);                      // GAP(x3), summed by the depthwise kernel
+    launch_gate_mlp(pool, nullptr, batch, ch, Ch, w1, b1, w2, b2, nullptr, gse, nullptr, 0, st);
+    launch_stats_finalize(ws, batch, P, ch, 1e-5f, m1, r1, st, gse);                        // the SE gate folded into the norm constants
+    launch_prep(u, batch, V, ch, m1, r1, 1, nullptr, SplitView{nullptr, 0, 0, 0}, y, nullptr, ws, SplitEnc{derr, ASCALE_DEFAULT}, st);
+    launch_nhwc_to_nchw(y, batch, ch, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));
     return MICA_OK;

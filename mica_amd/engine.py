@@ -337,6 +337,17 @@ class Engine:
                                                 b.ctypes.data_as(_cabi._FP), _ptr(y), self._stream()), "mica_op_depthwise3")
         return y
 
+    def op_se_depthwise(self, x, dw_w, dw_b, fc0_w, fc0_b, fc3_w, fc3_b):
+        """relu(IN(dwconv3(SE(relu(IN(x)))))) as the forward graph computes it (pool fused into the depthwise load, gate folded
+        into the norm constants)."""
+        x = _f32c(x, "x")
+        B, c, d, h, ww = x.shape
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (dw_w, dw_b, fc0_w, fc0_b, fc3_w, fc3_b)]
+        y = torch.empty_like(x)
+        self._check(self.lib.mica_op_se_depthwise(self._h, _ptr(x), B, c, d, h, ww, *[a.ctypes.data_as(_cabi._FP) for a in arrs], _ptr(y),
+                                                  self._stream()), "mica_op_se_depthwise")
+        return y
+
     def op_stem(self, m):
         m = _f32c(m, "map")
         B, one, d, h, w = m.shape

@@ -130,6 +130,24 @@ def test_depthwise(eng, c, dims, batch):
     assert rel_err(got, ref) < 1e-5
 
 
+@pytest.mark.parametrize("c,dims,batch", [(64, (8, 8, 8), 2), (128, (6, 9, 11), 2), (256, (3, 64, 64), 4)])     # the last: 32-channel workgroups
+def test_se_block_and_depthwise_local_branch(eng, c, dims, batch):
+    """SEBlock + the local branch of DualAttention (model.py:254-258, 80-82, 99) the way the graph runs them: the SE pool is
+    summed by the depthwise kernel while it loads, and the gate, which scales the depthwise conv's input in the reference,
+    is folded into the InstanceNorm constants of its output.  Against torch, operation by operation."""
+    x = _rand((batch, c, *dims), 41) * 2.0 + 0.3
+    dw_w = _rand((c, 1, 3, 3, 3), 42) * 0.3
+    dw_b = _rand((c,), 43) * 0.5                           # a sizeable bias: it must not be scaled by the gate
+    fc0_w, fc0_b = _rand((c // 16, c), 44) * (3.0 / c) ** 0.5 * 4, _rand((c // 16,), 45) * 0.1
+    fc3_w, fc3_b = _rand((c, c // 16), 46) * (3.0 * 16 / c) ** 0.5 * 4, _rand((c,), 47) * 0.5
+    x3 = F.relu(F.instance_norm(x, eps=1e-5))
+    g = torch.sigmoid(F.linear(F.relu(F.linear(x3.mean(dim=(2, 3, 4)), fc0_w, fc0_b)), fc3_w, fc3_b))
+    assert float(g.max() - g.min()) > 0.2                   # the gates really differ between channels
+    ref = F.relu(F.instance_norm(F.conv3d(x3 * g[:, :, None, None, None], dw_w, dw_b, padding=1, groups=c), eps=1e-5))
+    got = eng.op_se_depthwise(x.cuda(), dw_w.numpy().reshape(c, 27), dw_b.numpy(), fc0_w.numpy(), fc0_b.numpy(), fc3_w.numpy(), fc3_b.numpy())
+    assert rel_err(got, ref) < 5e-5                         # two InstanceNorms deep: float32 summation-order noise is ~1e-5
+
+
 @pytest.mark.parametrize("dims", [(8, 8, 8), (16, 16, 16), (5, 9, 33)])
 def test_stem(eng, weights, dims):
     x = _rand((2, 1, *dims), 11, 0.0, 1.0)
