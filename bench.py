@@ -246,22 +246,25 @@ def main():
         tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # re-collected whenever the conv kernels change
         if os.path.exists(tp) and B == 8 and not args.no_af:            # per launch at batch 8; independent of the map size
             traffic = json.load(open(tp)).get("kernels", {})
-        ach = flops / (ms * 1e-3) / 1e12
+        ach_all = flops / (ms * 1e-3) / 1e12
         wach = wflops / (wms * 1e-3) / 1e12 if wms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "conv_wino16_kernel (+ conv2_kernel for 1x1x1): dense 3x3x3 via Winograd F(2,3)-x, split-f16 x3 MFMA",
-                "achieved": ach, "peak": PEAK_SPLIT_TF, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TF,
+        roof = {"bound": "mfma", "kernel": "conv_wino16_kernel: every dense 3x3x3 conv via Winograd F(2,3)-x, split-f16 x3 MFMA (v_mfma_f32_16x16x32_f16)",
+                "achieved": wach, "peak": PEAK_SPLIT_TF, "unit": "TFLOP/s", "frac": wach / PEAK_SPLIT_TF,
                 "traffic": traffic.get("conv_wino16_kernel", {}).get("hbm_bytes"),
-                "launches_per_batch": launches, "avg_launch_ms": ms / max(launches, 1),
-                "algorithmic_gflop_per_launch_avg": flops / max(launches, 1) / 1e9,
+                "launches_per_batch": wl, "avg_launch_ms": wms / max(wl, 1),
+                "algorithmic_gflop_per_launch_avg": wflops / max(wl, 1) / 1e9,
                 "executed_mfma": {"achieved": wach * WINO_MFMA_PER_ALGORITHMIC, "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s (f16 MFMA issued)",
                                   "frac": wach * WINO_MFMA_PER_ALGORITHMIC / PEAK_F16_MFMA_TF,
-                                  "note": "3x3x3 layers only: algorithmic FLOPs / 1.5 (Winograd) x 3 (split products) x 14/13.5 (tap pairing) "
-                                          "= f16 MFMA FLOPs the kernel issues, over the 2.5 PF dense f16 peak"},
-                "note": "achieved = algorithmic direct-conv FLOPs (2*k^3*Cin*Cout*V, unpadded) / HIP-event time of the conv launches; "
-                        "peak = f16 dense MFMA 2500 TF / 3 MFMAs per f32-grade product (833 TF); with Winograd the kernel executes 1.5x fewer "
-                        "MFMAs than the algorithmic count, so this fraction is an algorithmic rate, `executed_mfma` is the hardware fraction; "
-                        "traffic = PMC HBM bytes per conv_wino16 launch at batch 8 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                        "gfx950 corrections, profiles/r02_pmc_traffic.json); null for other batch sizes"}
+                                  "note": "algorithmic FLOPs / 1.5 (Winograd) x 3 (split products) x 14/13.5 (tap pairing) = f16 MFMA FLOPs the "
+                                          "kernel issues, over the 2.5 PF dense f16 peak: the hardware fraction"},
+                "all_dense_convs": {"achieved": ach_all, "frac": ach_all / PEAK_SPLIT_TF, "launches_per_batch": launches,
+                                    "note": "3x3x3 and 1x1x1 launches together (the 1x1 kernel is HBM-bound and also does the operand passes)"},
+                "note": "achieved = algorithmic direct-conv FLOPs (2*27*Cin*Cout*V, unpadded) of the conv_wino16_kernel launches of one batch / their "
+                        "HIP-event time (avg_launch_ms = the mean over its 22 launches: compare profiles/r02_final_bench512_b8_kernel_stats.txt, "
+                        "three template variants); peak = f16 dense MFMA 2500 TF / 3 MFMAs per f32-grade product (833 TF); Winograd executes "
+                        "1.5x fewer MFMAs than the algorithmic count, so `frac` is an algorithmic rate and `executed_mfma` the hardware fraction; "
+                        "traffic = PMC HBM bytes per conv_wino16 launch at batch 8 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 "
+                        "corrections, profiles/r02_pmc_traffic.json); null for other batch sizes"}
         dach = dbytes / (dms * 1e-3) / 1e9
         hbm = {"bound": "hbm", "kernel": "depthwise_kernel (Conv3d groups=C, 3x3x3, IN+ReLU+SE gate fused on load, IN stats fused)",
                "achieved": dach, "peak": 8000.0, "unit": "GB/s", "frac": dach / 8000.0,
