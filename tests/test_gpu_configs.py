@@ -267,3 +267,44 @@ def test_config4_four_384_maps_streamed(eng):
         del d_vol, d_af
     # maps differ, so do their volumes (no buffer was reused across maps by mistake)
     assert not np.array_equal(got[0]["backbone_probability"], got[2]["backbone_probability"])
+
+
+def test_metric_config_512_map_whole_path_properties(eng):
+    """BASELINE.json's metric config at full size through the whole path: the synthetic 512^3 map with 24-channel AF3 encodings,
+    reference tiling (48, 8) -> 1331 windows, gather -> forward -> softmax/argmax -> stitch.  Size-independent properties: every
+    voxel written exactly once with a proper distribution, sampled tiles equal to a direct run of their batch, and a second
+    pass over the map reproduces the four volumes bit for bit (checksums)."""
+    from mica_amd._cabi import tile_table
+    from mica_amd.pipeline import VolumePredictor
+    n, B = 512, 8
+    vol = torch.from_numpy(np.random.default_rng(1002).random((n, n, n), dtype=np.float32)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(2001)
+    af = torch.empty((24, n, n, n), dtype=torch.float32, device="cuda")
+    for c in range(24):
+        af[c] = (torch.rand((n, n, n), generator=g, device="cuda") < 1e-3).float()
+    af[:, :, :, n // 2:] = 0                               # windows beyond z = 256 + halo see no atoms: both AF branches
+    vp = VolumePredictor(eng, 48, 8, batch=B)
+    out = vp.predict_volume(vol, af)
+    T = int(eng.lib.mica_tile_count(n, n, n, 48))
+    assert T == 1331
+    aa = out["amino_acid_probability"]
+    s = aa[:, ::5, ::7, ::3].sum(dim=0)
+    assert float((s - 1.0).abs().max()) < 1e-5             # a softmax everywhere: no voxel left at its initial zero
+    pred = out["amino_acid_prediction"]
+    assert float(pred.min()) >= 0 and float(pred.max()) <= 19 and bool((pred[::4, ::4, ::4] == pred[::4, ::4, ::4].round()).all())
+    for k in ("backbone_probability", "carbon_alpha_probability"):
+        assert float(out[k].min()) >= 0.0 and float(out[k].max()) <= 1.0 and float(out[k].max()) > 0.5
+    assert bool((pred == aa.argmax(dim=0).float()).float().mean() > 0.9999)      # prediction = first maximum of the stitched scores
+    tab = tile_table(n, n, n, 48)
+    for first in (0, 8 * 83, T - B - 3):                   # a corner batch, an interior batch across the AF boundary, the ragged end
+        rec = vp.run_batch(vol, af, first, B)
+        for q in range(B):
+            i, j, k, di, dj, dk = (int(v) for v in tab[first + q])
+            c = rec[q][:, 8:8 + di, 8:8 + dj, 8:8 + dk]
+            assert torch.equal(out["backbone_probability"][i:i + di, j:j + dj, k:k + dk], c[0])
+            assert torch.equal(aa[:, i:i + di, j:j + dj, k:k + dk], c[3:])
+    sums = {k: (float(v.double().sum()), float(v.double().pow(2).sum())) for k, v in out.items()}
+    del out, aa, pred
+    again = vp.predict_volume(vol, af)
+    for k, v in again.items():
+        assert (float(v.double().sum()), float(v.double().pow(2).sum())) == sums[k], k
