@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool (already exported there)
 
 FLOPS_PER_TILE_AF = 7.3625e12       # BASELINE.md section 3 (AF path), measured on the reference model
 PEAK_F16_MFMA_TF = 2500.0           # MI355X dense f16 MFMA (MI355X_MICROARCH.md)
@@ -290,6 +291,7 @@ def main():
                        "seconds_per_map": T / value},
             "alt_tiling": alt, "roofline": roof, "hbm_conv3d": hbm, "cpu_baseline": cpu}), flush=True)
     if world > 1:
+        dist.barrier()                          # rank 0 ran the extra profiled batch: leave together
         dist.destroy_process_group()
 
 
