@@ -308,3 +308,37 @@ def test_metric_config_512_map_whole_path_properties(eng):
     again = vp.predict_volume(vol, af)
     for k, v in again.items():
         assert (float(v.double().sum()), float(v.double().pow(2).sum())) == sums[k], k
+
+
+def test_command_line_entry_map_to_volumes(tmp_path, eng, weights):
+    """`python -m mica_amd --map ... --model ... --docked-model ... --out ...`: the disk-free chain behind a thin CLI, against
+    the same chain called step by step (non-trivial axis order in the header, anisotropic voxels)."""
+    from mica_amd import mrc
+    from mica_amd.pipeline import VolumePredictor
+    from mica_amd.preprocessing import DataPreprocessor
+    raw = ((synth_density((30, 36, 40), 27) - 0.3) * 2.0).astype(np.float32)
+    mp = str(tmp_path / "emd.mrc")
+    mrc.write_mrc(mp, raw, voxel_size=(1.25, 1.0, 1.5), origin=(1.0, 2.0, -1.0), mapc=2, mapr=1, maps=3, nxstart=3, nystart=4, nzstart=5)
+    pdb = tmp_path / "m_af3_docked.pdb"
+    rng = np.random.default_rng(9)
+    pdb.write_text("".join(_pdb_line(i + 1, ["N", "CA", "C", "O"][i % 4], "ALA", i // 4 + 1, *(rng.random(3) * 20 + 5)) for i in range(120)) + "END\n")
+    ck = str(tmp_path / "ckpt.pth")
+    _save_ckpt(ck, weights)
+    out = str(tmp_path / "out")
+    r = subprocess.run([sys.executable, "-m", "mica_amd", "--map", mp, "--model", ck, "--docked-model", str(pdb), "--out", out, "--batch", "4"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "sub-grids" in r.stdout and "offset [4.0, 3.0, 5.0]" in r.stdout       # [nx, ny, nz]start permuted like the axes
+    # the same chain, step by step
+    data, hd = mrc.read_mrc(mp)
+    dp = DataPreprocessor(mp, str(tmp_path / "af3"), quiet=True, engine=eng)
+    norm, _, _ = dp.normalize_array(np.asarray(data), hd.voxel_size, 1.0)
+    hdn = mrc.MrcHeader(nx=norm.shape[2], ny=norm.shape[1], nz=norm.shape[0], mapc=2, mapr=1, maps=3, nxstart=3, nystart=4, nzstart=5, origin=hd.origin)
+    vol, off = mrc.transpose_to_xyz(norm, hdn)
+    enc = dp.encode_AF3_volume(str(pdb), hd.origin, norm.shape).cpu().numpy()
+    af = np.stack([mrc.transpose_to_xyz(e, hdn)[0] for e in enc])
+    assert off == [4.0, 3.0, 5.0] and af.sum() > 50
+    ref = VolumePredictor(eng, 48, 8, 4).predict_volume(torch.from_numpy(np.ascontiguousarray(vol)).cuda(), torch.from_numpy(np.ascontiguousarray(af)).cuda())
+    for k, v in ref.items():
+        got = np.load(os.path.join(out, f"{k}.npy"))
+        assert got.dtype == np.float32 and np.array_equal(got, v.cpu().numpy()), k
