@@ -80,6 +80,12 @@ __device__ __forceinline__ const _Float16* chunk_base_wino(const ConvSrcs& s, in
 // Every LDS slot of a slab is rewritten per chunk (DMA, or an explicit zero for positions outside the volume).
 // ================================================================================================
 typedef float floatx4v __attribute__((ext_vector_type(4)));
+// development switch: -DMICA_EXP_NOEPI builds a kernel without the output-transform passes (timing experiments only)
+#ifdef MICA_EXP_NOEPI
+#define MICA_EXP_EPI_PASSES(n) 0
+#else
+#define MICA_EXP_EPI_PASSES(n) (n)
+#endif
 #ifndef MICA_BLOCKED_WALK
 #define MICA_BLOCKED_WALK 1
 #endif
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
             const int frow = lane / CG, fcg = lane % CG;
             const int P = (items_per_b / nnb) * 4;
 #pragma unroll
-            for (int pass = 0; pass < (SPLIT ? NCT : 4); ++pass) {
+            for (int pass = 0; pass < MICA_EXP_EPI_PASSES(SPLIT ? NCT : 4); ++pass) {
                 const int c0 = SPLIT ? pass : (pass >> 1) * 2;       // first column tile of the pass
                 const int wq = SPLIT ? 0 : (pass & 1);               // the group that writes T
                 if (SPLIT) {
