@@ -1,7 +1,7 @@
 // Dense convolution on gfx950 matrix cores: implicit GEMM over 16-channel chunks with split-f16 operands (x = hi + lo,
 // three f16 MFMA products per f32-grade product: lo*hi, hi*lo, hi*hi), which keeps ~22 mantissa bits per product at 3/16
-// of the f32-MFMA cost (MI355X: f32 MFMA 157 TF, f16 2.5 PF).  Replaces nn.Conv3d(k=3,pad=1) / nn.Conv3d(k=1) of reference
-// models/model.py:17,28,38,96,107,115,122,142,158-174,210,212.
+// of the f32-MFMA cost (MI355X: f32 MFMA 157 TF, f16 2.5 PF).  Replaces nn.Conv3d(k=3,pad=1) of reference
+// models/model.py:17,107,115,122,142,165-174,210,212.
 //   conv_wino16_kernel<128|64|32> : every 3^3 conv - Winograd F(2,3) along x, v_mfma_f32_16x16x32_f16, persistent
 // (the 1x1x1 convs are in kernels_conv1x1.hip)
 // Also here: weight packing, the depthwise 3^3 conv (model.py:80) and the Cin=1 multi-scale stem (model.py:9-14).
@@ -26,7 +26,7 @@ static bool first_use_on_device(unsigned long long& mask) {
 }
 
 // ================================================================================================
-// conv_wino: dense 3x3x3 conv with Winograd F(2,3) along x on top of the conv2 structure.  The kernel is
+// Winograd geometry shared by the kernel below: dense 3x3x3 conv with Winograd F(2,3) along x.  The kernel is
 // power/MFMA-issue bound (1.25 PF of f16 MFMA measured), so the lever left is fewer MFMAs: per output pair
 // 4 transform-domain products replace 6 taps => 9 (dz,dy) taps x 4 positions instead of 27 taps x 2 outputs
 // = 1.5x fewer MFMAs for the same result (products stay split-f16, accumulate f32; the transforms are
@@ -34,7 +34,7 @@ static bool first_use_on_device(unsigned long long& mask) {
 //   y[2i]   = m0 + m1 + m2          m_p = sum_{dz,dy,cin} t_p * u_p
 //   y[2i+1] = m1 - m2 - m3          u0 = g0, u1 = (g0+g1+g2)/2, u2 = (g0-g1+g2)/2, u3 = g2
 // Workgroup: 8 waves, output tile 16(x) = 8 pairs x 4(y) x 4(z); wave (p, wn) owns Winograd position p for
-// all 128 (pair,y,z) rows and 64 (BN/2) channels.  LDS image per chunk: 4 planes (hi/lo x k-half) x
+// all 128 (pair,y,z) rows and 64 channels.  LDS image per chunk: 4 planes (hi/lo x k-half) x
 // [z 6][p 4][y 6][pair 8] 16-B slots = 73,728 B, double buffered, filled by LDS-DMA; a row fragment is
 // (8 pairs x 4 y) of one z: y rows are 8 slots apart => every ds_read_b128 lane group covers 16 distinct slots.
 // Epilogue: the four position-waves exchange their accumulators through LDS and apply the output transform.
