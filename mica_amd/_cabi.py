@@ -69,6 +69,11 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # torch first: PyTorch-ROCm ships its own HIP runtime, and the process must hold ONE copy of it.  Loaded the other way round
+    # (this library first, pulling the system libamdhip64, then torch with its bundled one) the second runtime reports "no
+    # ROCm-capable device" to whoever got it.
+    import torch  # noqa: F401
+
     p = path or os.environ.get("MICA_HIP_LIB", LIB_PATH)
     if not os.path.exists(p):
         raise MicaHipError(
