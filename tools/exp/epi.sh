@@ -1,5 +1,6 @@
 #!/bin/bash
 # timing experiment: share of the output-transform epilogue in conv_wino16 (normal library vs a build without the passes)
+# build the variant first (in the container): make -C mica_amd/csrc exp_noepi ; delete tools/exp/libmica_noepi.so afterwards
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/epi
