@@ -486,3 +486,27 @@ def test_cluster_scores_nms_and_neighbour_matrix_bit_exact(eng):
     # both promotion branches of the last sum occur: distance term zero (3.3 <= dis <= 4.3) and non-zero
     inband = (rdis >= 2) & (rdis <= 6)
     assert ((np.abs(rdis - 3.8) <= 0.5) & inband).any() and ((np.abs(rdis - 3.8) > 0.5) & inband).any()
+
+
+@pytest.mark.parametrize("n,radius,seed", [(6000, 9, 1), (6000, 2.5, 2), (300, 30, 3), (1, 9, 4)])
+def test_nms_points_random_dense_clouds_vs_oracle(eng, n, radius, seed):
+    """mica_nms_points against the reference's greedy loop (modeler.py:822-831) on dense random candidate clouds: long chains of
+    'suppressed by a candidate that is itself suppressed' are what the round-based GPU formulation has to get right."""
+    from oracle import cluster_oracle as co
+    rng = np.random.default_rng(seed)
+    shape = (40, 36, 44)
+    lin = rng.choice(shape[0] * shape[1] * shape[2], size=n, replace=False)
+    pts = np.stack(np.unravel_index(lin, shape), axis=1).astype(np.int64)
+    score = rng.random(n)
+    order = np.argsort(-score)
+    pred = np.concatenate([score[order, None], pts[order].astype(np.float64)], axis=1)
+    ref = np.array(co.nms(pred.copy(), 0.0, radius)).reshape(-1, 3)
+    keep = eng.nms_points(torch.from_numpy(pts[order].astype(np.int32)).cuda(), shape, radius).cpu().numpy()
+    got = pts[order][keep]
+    assert np.array_equal(got, ref) and 0 < len(ref) <= n
+    from mica_amd.engine import MicaHipError
+    if n > 1:
+        dup = pts[order].astype(np.int32).copy()
+        dup[1] = dup[0]
+        with pytest.raises(MicaHipError, match="one voxel"):
+            eng.nms_points(torch.from_numpy(dup).cuda(), shape, radius)
