@@ -111,11 +111,12 @@ def _worker(rank, world, port, T, B, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("T,B", [(13, 4), (8, 4), (3, 4)])
-def test_sharded_records_gloo_world2(tmp_path, T, B):
-    port = 29500 + (os.getpid() + T) % 2000
+@pytest.mark.parametrize("T,B,world", [(13, 4, 2), (8, 4, 2), (3, 4, 2), (29, 4, 4), (5, 2, 3)])
+def test_sharded_records_gloo_world2(tmp_path, T, B, world):
+    """world 2 ... 4: more ranks than batches in the last round, ranks that get no batch at all ((3, 4, 2), (5, 2, 3))."""
+    port = 29500 + (os.getpid() + 7 * T + world) % 2000
     out = str(tmp_path / "got.pt")
-    mp.spawn(_worker, args=(2, port, T, B, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, T, B, out), nprocs=world, join=True)
     got = torch.load(out, weights_only=True)
     single = {}
     sharded_records(_producer, lambda rec, first: single.__setitem__(first, rec.clone()), T, B, (2, 4, 4, 4), torch.device("cpu"))
