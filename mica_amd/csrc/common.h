@@ -85,6 +85,8 @@ void launch_prep(const float* x, int B, int V, int C, const float* mean, const f
 // NCDHW f32 [B][C][V] -> split (C padded to 16, zero filled) ; also per-batch |x| sum
 void launch_prep_ncdhw(const float* x, int B, int V, int C, SplitView out, float* abs_sum, SplitEnc enc,
                        hipStream_t st);
+// abs_sum[b] += sum |x[b][0..n)| (x 16-byte aligned per batch entry when n % 4 == 0)
+void launch_abs_sum(const float* x, int B, int64_t n, float* abs_sum, hipStream_t st);
 void launch_finalize_sum(const float* ws, int B, int nblocks, int C, float inv, float* out, hipStream_t st);
 void launch_nchw_to_nhwc(const float* x, int B, int C, int V, float* y, hipStream_t st);
 void launch_nhwc_to_nchw(const float* x, int B, int C, int V, float* y, hipStream_t st);

@@ -408,7 +408,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     if (d_af && af_mode != MICA_AF_NONE) {
         // is_af_zero = af.abs().sum() < 1e-6  (model.py:60): device reduction, one small D2H per call
         HIPC(c, hipMemsetAsync(c->v_abs, 0, sizeof(float) * B, st));
-        launch_prep_ncdhw(d_af, B, V, 24, SplitView{nullptr, 0, 0, 0}, c->v_abs, SplitEnc{c->d_err, c->ascale}, st);
+        launch_abs_sum(d_af, B, (int64_t)24 * V, c->v_abs, st);
         HIPC(c, hipMemcpyAsync(c->h_abs, c->v_abs, sizeof(float) * B, hipMemcpyDeviceToHost, st));
         HIPC(c, hipStreamSynchronize(st));
         if (af_mode == MICA_AF_BATCH) {

@@ -952,7 +952,7 @@ int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, co
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st) {
     const int ntx = (d.W + DW_X - 1) / DW_X;
     // 32-channel workgroups (full 128-B lines) when that still gives every CU at least two rounds of work
-    if (C % 32 == 0 && (int64_t)ntx * ((d.H + 15) / 16) * (C / 32) * B >= 512) {
+    if (C % 32 == 0 && (int64_t)ntx * ((d.H + 15) / 16) * (C / 32) * B >= 256) {
         const int nty = (d.H + 15) / 16;
         launch_depthwise_t<4, 8>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, st);
         return ntx * nty;

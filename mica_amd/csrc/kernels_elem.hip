@@ -472,6 +472,32 @@ __global__ __launch_bounds__(256) void prep_ncdhw_kernel(const float* __restrict
     }
 }
 
+// sum |x| over each batch entry of a contiguous f32 tensor [B][n] (the AF3 test of model.py:60).  One float atomic per block:
+// the per-wave atomics of prep_ncdhw_kernel (65 K of them on 8 addresses) made that pass 6x slower than its traffic.
+__global__ __launch_bounds__(256) void abs_sum_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ abs_sum) {
+    __shared__ float sh[4];
+    const int b = blockIdx.y;
+    const float* xb = x + (int64_t)b * n;
+    float s = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(xb)[i];
+        s += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) s += fabsf(xb[n4 * 4 + threadIdx.x]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (t != 0.f) atomicAdd(abs_sum + b, t);
+    }
+}
+void launch_abs_sum(const float* x, int B, int64_t n, float* abs_sum, hipStream_t st) {
+    hipLaunchKernelGGL(abs_sum_kernel, dim3(128, B), dim3(256), 0, st, x, n, abs_sum);
+}
+
 void launch_prep_ncdhw(const float* x, int B, int V, int C, SplitView out, float* abs_sum, SplitEnc enc, hipStream_t st) {
     dim3 grid((V + 255) / 256, (C + 15) / 16, B);
     hipLaunchKernelGGL(prep_ncdhw_kernel, grid, dim3(256), 0, st, x, V, C, out, abs_sum, enc);
