@@ -34,6 +34,7 @@ SIGNATURES = {
     "mica_tile_count": (_L, [_L, _L, _L, _I]),
     "mica_tile_table": (_L, [_L, _L, _L, _I, _LP, _L]),
     "mica_gather_tiles": (_I, [_P, _P, _I, _L, _L, _L, _I, _I, _L, _L, _P, _P]),
+    "mica_gather_tiles_u8": (_I, [_P, _P, _I, _L, _L, _L, _I, _I, _L, _L, _P, _P]),
     "mica_stitch_tiles": (_I, [_P, _P, _I, _L, _L, _L, _I, _I, _L, _L, _P, _P]),
     "mica_normalise_map": (_I, [_P, _P, _L, _DP, _P]),
     "mica_zoom_cubic": (_I, [_P, _P, _L, _L, _L, _L, _L, _L, _P, _P]),

@@ -137,6 +137,8 @@ void launch_postprocess(const float* bb, const float* ca, const float* aa, int B
 
 void launch_gather_tiles(const float* vol, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
                          int64_t first, int64_t count, float* tiles, hipStream_t st);
+void launch_gather_tiles_u8(const uint8_t* vol, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
+                            int64_t first, int64_t count, float* tiles, hipStream_t st);
 void launch_stitch_tiles(const float* tiles, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
                          int64_t first, int64_t count, float* vol, hipStream_t st);
 // exact order statistics of a f32 array (radix select) ; see kernels_select.hip

@@ -755,6 +755,17 @@ int mica_gather_tiles(mica_ctx* c, const float* d_vol, int channels, int64_t n0,
     return MICA_OK;
 }
 
+int mica_gather_tiles_u8(mica_ctx* c, const uint8_t* d_vol, int channels, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
+                         int64_t first, int64_t count, float* d_tiles, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    int r = check_tiling(c, d_vol, d_tiles, channels, n0, n1, n2, grid, pad, first, count);
+    if (r || count == 0) return r;
+    HIPC(c, hipSetDevice(c->device));
+    launch_gather_tiles_u8(d_vol, channels, n0, n1, n2, grid, pad, first, count, d_tiles, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return MICA_OK;
+}
+
 int mica_stitch_tiles(mica_ctx* c, const float* d_tiles, int channels, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
                       int64_t first, int64_t count, float* d_vol, void* stream) {
     if (!c) return MICA_ERR_ARG;

@@ -724,7 +724,8 @@ void launch_fill_float(float* p, int64_t n, float v, hipStream_t st) {
 // volume; out-of-volume voxels read 0 (np.pad 'constant').  Pure copy => bit exact.
 // Stitch (predict.py:494-501): central grid^3 of every tile back into the volume; regions are disjoint.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gather_tiles_kernel(const float* __restrict__ vol, int C, int64_t n0, int64_t n1,
+template <typename TIn>
+__global__ __launch_bounds__(256) void gather_tiles_kernel(const TIn* __restrict__ vol, int C, int64_t n0, int64_t n1,
                                                            int64_t n2, int grid, int pad, int64_t first, int nt1, int nt2,
                                                            float* __restrict__ tiles) {
     const int W = grid + 2 * pad;
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(256) void gather_tiles_kernel(const float* __restri
     const int64_t tk = tg % nt2, tj = (tg / nt2) % nt1, ti = tg / ((int64_t)nt2 * nt1);
     const int64_t s0 = ti * grid + a0 - pad, s1 = tj * grid + a1 - pad, s2 = tk * grid + a2 - pad;
     float v = 0.f;
-    if (s0 >= 0 && s0 < n0 && s1 >= 0 && s1 < n1 && s2 >= 0 && s2 < n2) v = vol[(((int64_t)c * n0 + s0) * n1 + s1) * n2 + s2];
+    if (s0 >= 0 && s0 < n0 && s1 >= 0 && s1 < n1 && s2 >= 0 && s2 < n2) v = (float)vol[(((int64_t)c * n0 + s0) * n1 + s1) * n2 + s2];
     tiles[((int64_t)t * C + c) * W3 + e] = v;
 }
 void launch_gather_tiles(const float* vol, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad, int64_t first,
@@ -746,7 +747,16 @@ void launch_gather_tiles(const float* vol, int C, int64_t n0, int64_t n1, int64_
     int64_t W3 = (int64_t)W * W * W;
     int nt1 = (int)((n1 + grid - 1) / grid), nt2 = (int)((n2 + grid - 1) / grid);
     dim3 g((unsigned)((W3 + 255) / 256), C, (unsigned)count);
-    hipLaunchKernelGGL(gather_tiles_kernel, g, dim3(256), 0, st, vol, C, n0, n1, n2, grid, pad, first, nt1, nt2, tiles);
+    hipLaunchKernelGGL(gather_tiles_kernel<float>, g, dim3(256), 0, st, vol, C, n0, n1, n2, grid, pad, first, nt1, nt2, tiles);
+}
+// the same windows from a uint8 volume (binary AF3 encodings held at a quarter of the memory), converted to f32 on the way
+void launch_gather_tiles_u8(const uint8_t* vol, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad, int64_t first,
+                            int64_t count, float* tiles, hipStream_t st) {
+    int W = grid + 2 * pad;
+    int64_t W3 = (int64_t)W * W * W;
+    int nt1 = (int)((n1 + grid - 1) / grid), nt2 = (int)((n2 + grid - 1) / grid);
+    dim3 g((unsigned)((W3 + 255) / 256), C, (unsigned)count);
+    hipLaunchKernelGGL(gather_tiles_kernel<uint8_t>, g, dim3(256), 0, st, vol, C, n0, n1, n2, grid, pad, first, nt1, nt2, tiles);
 }
 
 __global__ __launch_bounds__(256) void stitch_tiles_kernel(const float* __restrict__ tiles, int C, int64_t n0, int64_t n1,

@@ -159,16 +159,23 @@ class Engine:
 
     # -- tiler / stitch / normalise -------------------------------------------------------------------
     def gather_tiles(self, vol: torch.Tensor, grid: int, pad: int, first: int, count: int, out=None):
-        """vol f32[C,N0,N1,N2] (or [N0,N1,N2]) -> tiles f32[count,C,W,W,W]."""
-        vol = _f32c(vol, "vol")
+        """vol f32 or uint8 [C,N0,N1,N2] (or [N0,N1,N2]) -> tiles f32[count,C,W,W,W].  uint8: binary AF3 encodings kept at a quarter
+        of the memory."""
+        if vol.dtype == torch.uint8:
+            if not vol.is_cuda:
+                raise MicaHipError(f"vol: expected a CUDA(HIP) tensor, got {vol.device}")
+            vol = vol.contiguous()
+            fn = self.lib.mica_gather_tiles_u8
+        else:
+            vol = _f32c(vol, "vol")
+            fn = self.lib.mica_gather_tiles
         if vol.dim() == 3:
             vol = vol[None]
         Cc, n0, n1, n2 = vol.shape
         W = grid + 2 * pad
         if out is None:
             out = torch.empty((count, Cc, W, W, W), dtype=torch.float32, device=self.device)
-        self._check(self.lib.mica_gather_tiles(self._h, _ptr(vol), Cc, n0, n1, n2, grid, pad, first, count, _ptr(out), self._stream()),
-                    "mica_gather_tiles")
+        self._check(fn(self._h, _ptr(vol), Cc, n0, n1, n2, grid, pad, first, count, _ptr(out), self._stream()), "mica_gather_tiles")
         return out
 
     def stitch_tiles(self, tiles: torch.Tensor, vol: torch.Tensor, grid: int, pad: int, first: int):

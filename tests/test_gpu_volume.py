@@ -510,3 +510,23 @@ def test_nms_points_random_dense_clouds_vs_oracle(eng, n, radius, seed):
         dup[1] = dup[0]
         with pytest.raises(MicaHipError, match="one voxel"):
             eng.nms_points(torch.from_numpy(dup).cuda(), shape, radius)
+
+
+def test_uint8_encoding_volume_equals_float32(eng):
+    """The 24 AF3 channels are binary, so a map's encodings may be held as uint8 (a quarter of the memory on every rank of a
+    sharded run): the gather converts on the way, tiles and the whole pipeline are bit-identical to the float32 volume."""
+    from mica_amd.pipeline import VolumePredictor
+    shape = (70, 50, 60)
+    af = synth_af(shape, 5, 0.01)
+    d32 = torch.from_numpy(af).cuda()
+    d8 = d32.to(torch.uint8)
+    T = int(eng.lib.mica_tile_count(*shape, 48))
+    for grid, pad in ((48, 8), (32, 16)):
+        Tg = int(eng.lib.mica_tile_count(*shape, grid))
+        assert torch.equal(eng.gather_tiles(d8, grid, pad, 1, Tg - 1), eng.gather_tiles(d32, grid, pad, 1, Tg - 1))
+    vol = torch.from_numpy(synth_density(shape, 6)).cuda()
+    vp = VolumePredictor(eng, 48, 8, batch=2)
+    a, b = vp.predict_volume(vol, d32), vp.predict_volume(vol, d8)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert T == 8
