@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--no-af", action="store_true", help="zero-AF path (exp_downsizing branch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-tiling", action="store_true")
+    ap.add_argument("--no-whole-map", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
@@ -232,6 +233,33 @@ def main():
         alt = {"tiling": "grid 48 + 2x8 halo (reference default)", "tiles_per_map": T48, "value": ks * B / d48,
                "unit": "sub-grids/s", "steps": ks, "seconds_per_map": T48 / (ks * B / d48)}
 
+    # one COMPLETE map, sustained: normalise (resample factor 1 + median/percentile select) -> gather -> forward -> softmax/argmax ->
+    # stitch over all windows of the reference tiling, wall clock with a device sync on both sides.  Outside the timed steps; it shows
+    # whether the rate of the short timed region holds over ~18 s of a power-bound kernel mix.
+    whole = None
+    if rank == 0 and world == 1 and not args.no_whole_map and S == 64:
+        vpw = VolumePredictor(eng, 48, 8, B)
+        Tw = int(eng.lib.mica_tile_count(n, n, n, 48))
+        del out
+        out = None
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        norm = eng.zoom_cubic(vol - 0.3, (1.0, 1.0, 1.0))           # preprocessing.py:117 runs zoom even at factor 1
+        eng.normalise_map_(norm)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        vols = vpw.predict_volume(norm, af)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        chk = float(vols["amino_acid_probability"][:, ::16, ::16, ::16].sum(dim=0).sub(1).abs().max())
+        whole = {"map": f"{n}^3", "tiling": "grid 48 + 2x8 halo (reference default)", "tiles": Tw, "seconds": t3 - t1,
+                 "normalise_seconds": t2 - t1, "predict_seconds": t3 - t2, "value": Tw / (t3 - t2), "unit": "sub-grids/s",
+                 "value_incl_normalise": Tw / (t3 - t1), "softmax_sum_check": chk,
+                 "note": "one complete map, every window, wall clock; `value` = tiles / (gather+forward+softmax+stitch seconds), the "
+                         "same scope as the headline value (compare alt_tiling, the same tiling over a short window)"}
+        del vols, norm
+        out = torch.zeros((23, n, n, n), dtype=torch.float32, device=dev)
+
     # rooflines: HIP events (on the launch stream, inside the library) around every dense-conv and every depthwise
     # conv3d launch of one extra, untimed batch.  PMC traffic comes from the committed rocprofv3 passes (profiles/).
     roof = hbm = None
@@ -286,10 +314,13 @@ def main():
             "vs_baseline": None, "dtype": "f32 (3x f16 MFMA split products, f32 accumulate)", "data": "synthetic",
             "config": {"workload": f"synthetic {n}^3 density map + 24-ch AF3 encodings, window 64 = grid {args.grid} + 2x{args.pad} halo, "
                                    f"{T} tiles per map, {B} tiles per step per GPU, gather+forward+softmax+stitch"
-                                   + ("" if world == 1 else ", RCCL all-gather of cropped records to every rank, rank 0 stitches"),
+                                   + ("" if world == 1 else f", {'RCCL' if args.backend == 'nccl' else args.backend + ' (rehearsal, host-staged)'} "
+                                      "all-gather of cropped records to every rank, rank 0 stitches")
+                                   + (", every rank on cuda:0" if args.single_device else ""),
+                       "backend": None if world == 1 else args.backend,
                        "tiles_per_step": B * world, "af_path": not args.no_af, "flops_per_tile": FLOPS_PER_TILE_AF,
                        "seconds_per_map": T / value},
-            "alt_tiling": alt, "roofline": roof, "hbm_conv3d": hbm, "cpu_baseline": cpu}), flush=True)
+            "alt_tiling": alt, "whole_map": whole, "roofline": roof, "hbm_conv3d": hbm, "cpu_baseline": cpu}), flush=True)
     if world > 1:
         dist.barrier()                          # rank 0 ran the extra profiled batch: leave together
         dist.destroy_process_group()

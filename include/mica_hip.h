@@ -103,12 +103,29 @@ int mica_stitch_tiles(mica_ctx* ctx, const float* d_tiles, int channels, int64_t
  * reports "No positive values" / "Percentile value is zero" (preprocessing.py:159-165).      */
 int mica_normalise_map(mica_ctx* ctx, float* d_vol, int64_t n, double* h_stats, void* stream);
 
+/* MRC data modes the reference accepts besides float32 (it hands whatever dtype mrcfile returns to scipy and numpy,
+ * preprocessing.py:98-133): mode 0 = int8, 1 = int16, 6 = uint16.  The caller passes the integers converted to f32 (exact)
+ * and names the type; the arithmetic then follows what numpy / scipy do with an integer array:
+ *   zoom      - scipy keeps the input dtype: the f64 spline result is rounded half away from zero and clamped to the type
+ *               (the values stay f32 in d_out);
+ *   normalise - np.median of integers is float64 and `norm_data - median` (:124) promotes the whole computation to float64:
+ *               float64 percentile interpolation, clip and division, one rounding to float32 at :139.
+ * (mode 12, float16: scipy.ndimage refuses the dtype, so the reference reports failure and so does the caller here.)      */
+#define MICA_MAP_F32 0
+#define MICA_MAP_I8 1
+#define MICA_MAP_I16 2
+#define MICA_MAP_U16 3
+int mica_normalise_map_typed(mica_ctx* ctx, float* d_vol, int64_t n, int map_type, double* h_stats, void* stream);
+
 /* ---- resampler: scipy.ndimage.zoom(data, factors, order=3) as called at preprocessing.py:117 ---- */
 /* d_in f32[n0][n1][n2] -> d_out f32[o0][o1][o2], o = int(round(n * factor)) chosen by the caller exactly as scipy does
  * (mode='constant', cval=0, prefilter=True, grid_mode=False).  f64 internally, bit-exact against scipy 1.15.3.
  * Synchronous; allocates an f64 copy of the input for the call.                                   */
 int mica_zoom_cubic(mica_ctx* ctx, const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1,
                     int64_t o2, float* d_out, void* stream);
+/* The same for an integer map held as f32 (map_type = MICA_MAP_*, above): scipy's integer output conversion applied. */
+int mica_zoom_cubic_typed(mica_ctx* ctx, const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1,
+                          int64_t o2, int map_type, float* d_out, void* stream);
 
 /* ---- AF3 encoding rasteriser: the atom loop of create_AF3_encodings (preprocessing.py:172-178, 283-298) ---- */
 /* d_xyz f32[n][3] atom coordinates (Angstrom, as Bio.PDB's float32 get_coord()), d_bb int32[n] = backbone channel 0..3
@@ -121,9 +138,8 @@ int mica_rasterise_atoms(mica_ctx* ctx, const float* d_xyz, const int32_t* d_bb,
                          const float* h_origin, int64_t nz, int64_t ny, int64_t nx, float* d_vol, void* stream);
 
 /* ---- point lists for the consumer of the volumes: Solver.clustering (utils/modeler.py:762-858) ---------------- */
-/* The three steps of it that touch whole volumes, so that only the candidate points leave the GPU.  DBSCAN (open3d,
- * :770), the cluster scores and the greedy non-maximum suppression (:822-831) work on the point list and stay with the
- * caller.
+/* Every step of it except DBSCAN (open3d, :770), the argsort of the candidate list and the scalar decisions on per-cluster
+ * numbers, which stay with the caller (mica_amd/clustering.py shows the split); only point lists leave the GPU.
  * np.array(np.where(vol > thr)).T (:767) as ascending linear indices into d_vol f32[n] (= lexicographic (x, y, z) order);
  * writes at most `capacity` of them, *h_count = how many there are.  Synchronous.                                  */
 int mica_threshold_points(mica_ctx* ctx, const float* d_vol, int64_t n, float thr, int64_t* d_idx, int64_t capacity,
@@ -183,11 +199,15 @@ int mica_op_se_depthwise(mica_ctx* ctx, const float* d_x, int batch, int c, int 
 int mica_op_stem(mica_ctx* ctx, const float* d_map, int batch, int d, int h, int w, float* d_y, void* stream);
 
 /* Activation scale of the split-f16 operand encoding (x * scale = hi + lo in f16): 16 after mica_create.  When an
- * activation exceeds the f16 range at the current scale (|x| > 60000 / scale, i.e. 3750 at 16) mica_forward_* repeat the
- * forward at scale / 4 - exact: powers of two, undone in the conv epilogues - and the context keeps the lower scale;
- * only NaN/Inf, or |x| > 1.5e7 (scale 2^-8), end in MICA_ERR_RANGE.  The reference (fp32 PyTorch) has no such limit.
- * The setter takes a power of two in [2^-8, 16] (tests; or to return to 16 after an outlier map).                  */
+ * activation of a tile exceeds the f16 range at the context's scale (|x| > 60000 / scale, i.e. 3750 at 16) mica_forward_*
+ * repeat THAT tile at scale / 4, / 16 ... - exact: powers of two, undone in the conv epilogues - for this call only: the other
+ * tiles of the batch keep the numbers they have alone, the context's scale does not change, and later calls start from it
+ * again.  Only NaN/Inf, or |x| > 1.5e7 (scale 2^-8), end in MICA_ERR_RANGE.  The reference (fp32 PyTorch) has no such limit;
+ * at scales below 1/4 the lo halves lose bits (whole-network error up to ~2e-4 instead of < 1e-4), which is
+ * why mica_get_last_forward_scale() reports the lowest scale the last forward call had to use (mica_amd/engine.py warns).
+ * The setter takes a power of two in [2^-8, 16] as the scale every call starts from (tests; un-normalised inputs).     */
 float mica_get_activation_scale(const mica_ctx* ctx);
+float mica_get_last_forward_scale(const mica_ctx* ctx);
 int mica_set_activation_scale(mica_ctx* ctx, float scale);
 
 /* ---- introspection for bench.py ----------------------------------------------------------- */

@@ -38,6 +38,8 @@ SIGNATURES = {
     "mica_stitch_tiles": (_I, [_P, _P, _I, _L, _L, _L, _I, _I, _L, _L, _P, _P]),
     "mica_normalise_map": (_I, [_P, _P, _L, _DP, _P]),
     "mica_zoom_cubic": (_I, [_P, _P, _L, _L, _L, _L, _L, _L, _P, _P]),
+    "mica_normalise_map_typed": (_I, [_P, _P, _L, _I, _DP, _P]),
+    "mica_zoom_cubic_typed": (_I, [_P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P]),
     "mica_rasterise_atoms": (_I, [_P, _P, _P, _P, _L, _FP, _L, _L, _L, _P, _P]),
     "mica_threshold_points": (_I, [_P, _P, _L, _F, _P, _L, _LP, _P]),
     "mica_gather_values": (_I, [_P, _P, _I, _L, _P, _L, _P, _P]),
@@ -52,6 +54,7 @@ SIGNATURES = {
     "mica_op_se_depthwise": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _FP, _FP, _FP, _FP, _P, _P]),
     "mica_op_stem": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "mica_get_activation_scale": (_F, [_P]),
+    "mica_get_last_forward_scale": (_F, [_P]),
     "mica_set_activation_scale": (_I, [_P, _F]),
     "mica_set_profiling": (_I, [_P, _I]),
     "mica_get_conv_profile": (_I, [_P, _DP, _LP, _DP]),

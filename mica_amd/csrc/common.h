@@ -4,6 +4,8 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include "../../include/mica_hip.h"
+
 namespace mica {
 
 // ---- activation formats ----------------------------------------------------------------------
@@ -101,7 +103,7 @@ void launch_fill_float(float* p, int64_t n, float v, hipStream_t st);
 // depthwise 3^3 on raw input with fused (x-mean)*rstd, relu, *scale applied on load (zero padding after)
 // C must be a multiple of 16.  stats_ws (nullable): fused InstanceNorm partials, returns their count P.
 // gap_ws (nullable): f32 [B][P][C] per-block sums of the normalised input over the block's own voxels (launch_finalize_sum).
-int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
+int launch_depthwise(const float* x, int B, int Bplan, Dims d, int C, const float* mean, const float* rstd,
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st);
 // merge P partials f32 [B][P][C][3] = (count, mean, M2) into mean / rstd.  gate f32 [B][C] (nullable): the statistics are
 // those of u while the tensor that is normalised downstream is t = g u + const (g > 0 per tile and channel): then
@@ -111,7 +113,7 @@ void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, floa
 int64_t fused_stats_ws_floats(int B, int tile_size);
 // stem: map f32 [B][V] -> split view of 128 channels + gap[b][128] (mean over voxels)
 void launch_stem(const float* map, int B, Dims d, const float* wstem, const float* bstem, SplitView out,
-                 float* out_raw, float* gap, float* ws, float ascale, hipStream_t st);
+                 float* out_raw, float* gap, float* ws, SplitEnc enc, hipStream_t st);
 int64_t stem_weight_floats();
 // x_feat raw [B][V][64] -> split(x_feat * sigmoid(w2 . relu(W0 x + b0) + b2))
 void launch_feat_gate(const float* x, int B, int V, const float* w0, const float* b0, const float* w2,
@@ -142,9 +144,9 @@ void launch_gather_tiles_u8(const uint8_t* vol, int C, int64_t n0, int64_t n1, i
 void launch_stitch_tiles(const float* tiles, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
                          int64_t first, int64_t count, float* vol, hipStream_t st);
 // exact order statistics of a f32 array (radix select) ; see kernels_select.hip
-int normalise_map_device(float* d_vol, int64_t n, double* h_stats, hipStream_t st, char* err, int errlen);
+int normalise_map_device(float* d_vol, int64_t n, int kind, double* h_stats, hipStream_t st, char* err, int errlen);
 // scipy.ndimage.zoom(order=3) restated bit-exactly in f64 ; see kernels_zoom.hip (synchronous)
-int zoom_cubic_device(const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1, int64_t o2, float* d_out,
+int zoom_cubic_device(const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1, int64_t o2, int kind, float* d_out,
                       hipStream_t st, char* err, int errlen);
 
 // AF3 encoding rasteriser (preprocessing.py:172-178,283-298) ; zeroes d_vol f32[24][nz][ny][nx] first ; synchronous

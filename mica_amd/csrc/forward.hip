@@ -92,7 +92,9 @@ struct mica_ctx {
     float* ws_gap = nullptr;      // depthwise: per-block sums of its normalised input [B][blocks][C]
     float *v_mean, *v_rstd, *v_mean3, *v_rstd3, *v_pool, *v_gse, *v_gate, *v_abs;
     int* d_err = nullptr;
-    float ascale = ASCALE_DEFAULT;   // activation scale of the split encoding (common.h); lowered by forward_checked on overflow
+    float ascale = ASCALE_DEFAULT;   // activation scale of the split encoding (common.h) every forward call starts from
+    float last_scale = ASCALE_DEFAULT;   // the lowest scale a tile of the last forward call needed (forward_checked)
+    std::vector<char> use_af;        // per tile of the last forward_impl call: AF3 branch taken
     float* h_abs = nullptr;       // pinned
     int* h_err = nullptr;         // pinned
 
@@ -316,7 +318,7 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
     const Dims d = c->d;
     SplitView none{nullptr, 0, 0, 0};
     // ---- MultiScaleInput (model.py:43-74) ------------------------------------------------------
-    launch_stem(d_map, B, d, c->stem_w, c->stem_b, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, c->ws, c->ascale, st);
+    launch_stem(d_map, B, d, c->stem_w, c->stem_b, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, c->ws, SplitEnc{c->d_err, c->ascale}, st);
     if (!use_af) {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->downsizing.d_cin_scale, 128, st);
         run_conv1x1(c, c->downsizing, split_src(c->S_exp, 8, 0, 8), nullptr, view(c->S_x0, 4, 0, 4), c->R_a, B, st);
@@ -349,7 +351,7 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         // DualAttention (model.py:98-101): local branch
         {
             prof_begin(c, 1, st);
-            const int P = launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, nullptr, E.dw_w, E.dw_b, c->R_c, c->ws, c->ws_gap, st);
+            const int P = launch_depthwise(c->R_b, B, c->maxB, d, C, c->v_mean3, c->v_rstd3, nullptr, E.dw_w, E.dw_b, c->R_c, c->ws, c->ws_gap, st);
             prof_end(c, 1, 8.0 * (double)C * V * B, st);     // algorithmic bytes: read + write 4 B per voxel and channel
             launch_finalize_sum(c->ws_gap, B, P, C, 1.0f / (float)V, c->v_pool, st);
             gate(c, E.se, c->v_pool, nullptr, B, nullptr, c->v_gse, nullptr, 0, st);      // SEBlock gate (model.py:254-258)
@@ -394,7 +396,7 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
 }
 
 int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int af_mode, float* o_bb, float* o_ca, float* o_aa,
-                 hipStream_t st) {
+                 hipStream_t st, const char* force_use = nullptr) {
     if (!c->finalized) { c->err = "weights not finalized"; return MICA_ERR_STATE; }
     if (B < 1 || B > c->maxB) { c->err = "batch out of range [1, max_batch]"; return MICA_ERR_ARG; }
     if (!d_map || !o_bb || !o_ca || !o_aa) { c->err = "null pointer argument"; return MICA_ERR_ARG; }
@@ -405,7 +407,9 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     for (double& w : c->prof_work) w = 0;
     HIPC(c, hipMemsetAsync(c->d_err, 0, sizeof(int), st));
     std::vector<char> use(B, 0);
-    if (d_af && af_mode != MICA_AF_NONE) {
+    if (force_use) {
+        for (int b = 0; b < B; ++b) use[b] = force_use[b];
+    } else if (d_af && af_mode != MICA_AF_NONE) {
         // is_af_zero = af.abs().sum() < 1e-6  (model.py:60): device reduction, one small D2H per call
         HIPC(c, hipMemsetAsync(c->v_abs, 0, sizeof(float) * B, st));
         launch_abs_sum(d_af, B, (int64_t)24 * V, c->v_abs, st);
@@ -419,6 +423,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
             for (int b = 0; b < B; ++b) use[b] = !(c->h_abs[b] < 1e-6f);
         }
     }
+    c->use_af = use;
     for (int b0 = 0; b0 < B;) {
         int b1 = b0 + 1;
         while (b1 < B && use[b1] == use[b0]) ++b1;
@@ -461,27 +466,51 @@ bool pow2_8_512(int c) { return c >= 8 && c <= 512 && (c & (c - 1)) == 0; }
 }  // namespace
 
 
-// The forward with the range check of the split-f16 encoding (synchronises `st`).  An activation beyond the f16 range at
-// the current activation scale (|x| * ascale > 60000) repeats the forward at ascale / 4 - exact, the epilogues undo the
-// power of two - and the lower scale stays with the context (small steps: below ~1 the lo halves of O(1) activations go
-// subnormal in f16 and the whole-network error grows, 5.6e-5 at scale 1 -> 1.2e-4 at 1/16 on the synthetic weights); NaN/Inf, or an overflow at the smallest scale, fail loudly
-// with MICA_ERR_RANGE rather than return clipped numbers.
+// The forward with the range check of the split-f16 encoding (synchronises `st`).  An activation beyond the f16 range at the
+// context's activation scale (|x| * ascale > 60000) is handled PER TILE and PER CALL: the tiles of the batch are repeated one
+// by one, each from the context's scale again, and only a tile that overflows alone steps down by 4 (exact: powers of two,
+// undone in the conv epilogues) until it fits.  A tile's numbers therefore never depend on its batch neighbours, on tiles or
+// maps processed earlier, or on which rank of a sharded run met the outlier; the context's scale is not changed.  Below ~1 the
+// lo halves of O(1) activations go subnormal in f16 and the whole-network error grows (DESIGN.md section 2 has the measured
+// table); mica_get_last_forward_scale() reports the lowest scale the call used so that the caller can tell.  NaN/Inf, or an
+// overflow at the smallest scale, fail loudly with MICA_ERR_RANGE rather than return clipped numbers.
+static int range_flag(mica_ctx* c, hipStream_t st, int* flag) {
+    HIPC(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPC(c, hipStreamSynchronize(st));
+    *flag = *c->h_err;
+    return MICA_OK;
+}
+static int range_error(mica_ctx* c, int flag) {
+    c->err = (flag & RANGE_NONFINITE) ? "activation outside the representable range of the split-f16 conv path: NaN/Inf in the input or in an activation"
+                                      : "activation outside the representable range of the split-f16 conv path (|x| > 1.5e7)";
+    return MICA_ERR_RANGE;
+}
 static int forward_checked(mica_ctx* c, const float* d_map, const float* d_af, int B, int af_mode, float* o_bb, float* o_ca,
                            float* o_aa, hipStream_t st) {
-    for (;;) {
-        int r = forward_impl(c, d_map, d_af, B, af_mode, o_bb, o_ca, o_aa, st);
-        if (r) return r;
-        HIPC(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPC(c, hipStreamSynchronize(st));
-        const int flag = *c->h_err;
-        if (!flag) return MICA_OK;
-        if ((flag & RANGE_NONFINITE) || c->ascale <= ASCALE_MIN) {
-            c->err = (flag & RANGE_NONFINITE) ? "activation outside the representable range of the split-f16 conv path: NaN/Inf in the input or in an activation"
-                                              : "activation outside the representable range of the split-f16 conv path (|x| > 1.5e7)";
-            return MICA_ERR_RANGE;
+    const float base = c->ascale;
+    c->last_scale = base;
+    int flag = 0;
+    int r = forward_impl(c, d_map, d_af, B, af_mode, o_bb, o_ca, o_aa, st);
+    if (r || (r = range_flag(c, st, &flag))) return r;
+    if (!flag) return MICA_OK;
+    if (flag & RANGE_NONFINITE) return range_error(c, flag);
+    const std::vector<char> use = c->use_af;          // the gate decisions of the whole call (MICA_AF_BATCH looks at all tiles)
+    const int V = c->V;
+    for (int b = 0; b < B && !r; ++b) {
+        // a single tile that overflowed at `base` has nothing new to learn there
+        c->ascale = (B == 1) ? base * 0.25f : base;
+        for (;;) {
+            if (c->ascale < ASCALE_MIN) { r = range_error(c, RANGE_OVERFLOW); break; }
+            r = forward_impl(c, d_map + (int64_t)b * V, d_af ? d_af + (int64_t)b * 24 * V : nullptr, 1, af_mode, o_bb + (int64_t)b * 4 * V,
+                             o_ca + (int64_t)b * 4 * V, o_aa + (int64_t)b * 21 * V, st, &use[b]);
+            if (r || (r = range_flag(c, st, &flag))) break;
+            if (!flag) { c->last_scale = std::min(c->last_scale, c->ascale); break; }
+            if (flag & RANGE_NONFINITE) { r = range_error(c, flag); break; }
+            c->ascale *= 0.25f;
         }
-        c->ascale *= 0.25f;
     }
+    c->ascale = base;
+    return r;
 }
 
 // =================================================================================================
@@ -777,30 +806,42 @@ int mica_stitch_tiles(mica_ctx* c, const float* d_tiles, int channels, int64_t n
     return MICA_OK;
 }
 
-int mica_normalise_map(mica_ctx* c, float* d_vol, int64_t n, double* h_stats, void* stream) {
+int mica_normalise_map_typed(mica_ctx* c, float* d_vol, int64_t n, int map_type, double* h_stats, void* stream) {
     if (!c) return MICA_ERR_ARG;
-    if (!d_vol || n < 1 || !h_stats) { c->err = "mica_normalise_map: bad argument"; return MICA_ERR_ARG; }
+    if (!d_vol || n < 1 || !h_stats || map_type < MICA_MAP_F32 || map_type > MICA_MAP_U16) {
+        c->err = "mica_normalise_map: bad argument";
+        return MICA_ERR_ARG;
+    }
     HIPC(c, hipSetDevice(c->device));
     char buf[256] = {0};
-    int r = normalise_map_device(d_vol, n, h_stats, (hipStream_t)stream, buf, sizeof(buf));
+    int r = normalise_map_device(d_vol, n, map_type, h_stats, (hipStream_t)stream, buf, sizeof(buf));
+    if (r) c->err = buf;
+    return r;
+}
+
+int mica_normalise_map(mica_ctx* c, float* d_vol, int64_t n, double* h_stats, void* stream) {
+    return mica_normalise_map_typed(c, d_vol, n, MICA_MAP_F32, h_stats, stream);
+}
+
+int mica_zoom_cubic_typed(mica_ctx* c, const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1, int64_t o2,
+                          int map_type, float* d_out, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    const int64_t lim = 4096;
+    if (!d_in || !d_out || n0 < 1 || n1 < 1 || n2 < 1 || o0 < 1 || o1 < 1 || o2 < 1 || n0 > lim || n1 > lim || n2 > lim || o0 > lim ||
+        o1 > lim || o2 > lim || map_type < MICA_MAP_F32 || map_type > MICA_MAP_U16) {
+        c->err = "mica_zoom_cubic: bad argument";
+        return MICA_ERR_ARG;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    char buf[256] = {0};
+    int r = zoom_cubic_device(d_in, n0, n1, n2, o0, o1, o2, map_type, d_out, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
     return r;
 }
 
 int mica_zoom_cubic(mica_ctx* c, const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1, int64_t o2,
                     float* d_out, void* stream) {
-    if (!c) return MICA_ERR_ARG;
-    const int64_t lim = 4096;
-    if (!d_in || !d_out || n0 < 1 || n1 < 1 || n2 < 1 || o0 < 1 || o1 < 1 || o2 < 1 || n0 > lim || n1 > lim || n2 > lim || o0 > lim ||
-        o1 > lim || o2 > lim) {
-        c->err = "mica_zoom_cubic: bad argument";
-        return MICA_ERR_ARG;
-    }
-    HIPC(c, hipSetDevice(c->device));
-    char buf[256] = {0};
-    int r = zoom_cubic_device(d_in, n0, n1, n2, o0, o1, o2, d_out, (hipStream_t)stream, buf, sizeof(buf));
-    if (r) c->err = buf;
-    return r;
+    return mica_zoom_cubic_typed(c, d_in, n0, n1, n2, o0, o1, o2, MICA_MAP_F32, d_out, stream);
 }
 
 int mica_rasterise_atoms(mica_ctx* c, const float* d_xyz, const int32_t* d_bb, const int32_t* d_aa, int64_t n_atoms,
@@ -1056,7 +1097,7 @@ int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, 
     HIPC(c, hipMemcpy(dw, wt.data(), sizeof(float) * 27 * ch, hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(db, h_b, sizeof(float) * ch, hipMemcpyHostToDevice));
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
-    launch_depthwise(a, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, nullptr, nullptr, st);
+    launch_depthwise(a, batch, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, nullptr, nullptr, st);
     launch_nhwc_to_nchw(b, batch, ch, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));
@@ -1102,7 +1143,7 @@ int mica_op_se_depthwise(mica_ctx* c, const float* d_x, int batch, int ch, int d
     HIPC(c, hipMemsetAsync(derr, 0, 4, st));
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
     launch_stats(a, batch, V, ch, 1e-5f, m0, r0, ws, st);                                  // x3 = relu(IN(x)) is applied on load
-    const int P = launch_depthwise(a, batch, dm, ch, m0, r0, nullptr, dw, db, u, ws, wsg, st);
+    const int P = launch_depthwise(a, batch, batch, dm, ch, m0, r0, nullptr, dw, db, u, ws, wsg, st);
     launch_finalize_sum(wsg, batch, P, ch, 1.0f / (float)V, pool, st);                      // GAP(x3), summed by the depthwise kernel
     launch_gate_mlp(pool, nullptr, batch, ch, Ch, w1, b1, w2, b2, nullptr, gse, nullptr, 0, st);
     launch_stats_finalize(ws, batch, P, ch, 1e-5f, m1, r1, st, gse);                        // the SE gate folded into the norm constants
@@ -1123,7 +1164,7 @@ int mica_op_stem(mica_ctx* c, const float* d_map, int batch, int d, int h, int w
     Tmp t;
     float* raw = t.get<float>((int64_t)batch * V * 128);
     if (!raw) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
-    launch_stem(d_map, batch, Dims{d, h, w}, c->stem_w, c->stem_b, SplitView{nullptr, 0, 0, 0}, raw, nullptr, nullptr, ASCALE_DEFAULT, st);
+    launch_stem(d_map, batch, Dims{d, h, w}, c->stem_w, c->stem_b, SplitView{nullptr, 0, 0, 0}, raw, nullptr, nullptr, SplitEnc{nullptr, ASCALE_DEFAULT}, st);
     launch_nhwc_to_nchw(raw, batch, 128, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));
@@ -1131,6 +1172,7 @@ int mica_op_stem(mica_ctx* c, const float* d_map, int batch, int d, int h, int w
 }
 
 float mica_get_activation_scale(const mica_ctx* c) { return c ? c->ascale : 0.f; }
+float mica_get_last_forward_scale(const mica_ctx* c) { return c ? c->last_scale : 0.f; }
 
 int mica_set_activation_scale(mica_ctx* c, float scale) {
     if (!c) return MICA_ERR_ARG;

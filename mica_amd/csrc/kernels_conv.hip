@@ -948,17 +948,19 @@ static void launch_depthwise_t(const float* x, int B, Dims d, int C, const float
     dim3 grid((unsigned)(ntx * nty * (C / Gm::DWC)), B);
     hipLaunchKernelGGL((depthwise_kernel<YO, CQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty);
 }
-int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
+int launch_depthwise(const float* x, int B, int Bplan, Dims d, int C, const float* mean, const float* rstd,
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st) {
     const int ntx = (d.W + DW_X - 1) / DW_X;
+    // The variant fixes the number and order of the statistics / pool partials of a tile, so it is chosen from the context's
+    // batch capacity (Bplan), never from the size of this call: a tile's numbers do not depend on how many tiles share its call.
     // 32-channel workgroups (full 128-B lines) when that still gives every CU at least two rounds of work
-    if (C % 32 == 0 && (int64_t)ntx * ((d.H + 15) / 16) * (C / 32) * B >= 256) {
+    if (C % 32 == 0 && (int64_t)ntx * ((d.H + 15) / 16) * (C / 32) * Bplan >= 256) {
         const int nty = (d.H + 15) / 16;
         launch_depthwise_t<4, 8>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, st);
         return ntx * nty;
     }
     // enough workgroups to fill 256 CUs twice: halve the column height when C * batch is small
-    const bool small = (int64_t)ntx * ((d.H + 15) / 16) * (C / 16) * B < 1024;
+    const bool small = (int64_t)ntx * ((d.H + 15) / 16) * (C / 16) * Bplan < 1024;
     const int Y = small ? 8 : 16;
     const int nty = (d.H + Y - 1) / Y;
     if (small) launch_depthwise_t<2, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, st);
@@ -1004,8 +1006,10 @@ __device__ __forceinline__ void stem_one(const float* __restrict__ tile, const f
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ map, Dims d,
                                                    const float* __restrict__ wstem, const float* __restrict__ bstem,
                                                    SplitView out, float* __restrict__ out_raw,
-                                                   float* __restrict__ ws, int ntx, int nty, float ascale) {
+                                                   float* __restrict__ ws, int ntx, int nty, SplitEnc enc) {
     __shared__ float tile[ST_LZ * ST_LY * ST_LX];
+    const float ascale = enc.ascale;
+    int bad = 0;
     __shared__ float csum[4][128];   // per-wave partial channel sums (fixed summation order => deterministic)
     const int tid = threadIdx.x, b = blockIdx.y;
     const int V = d.D * d.H * d.W;
@@ -1051,6 +1055,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ map
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
                             float xs = acc[v][cc * 16 + j] * ascale;
+                            if (!(fabsf(xs) <= F16_LIMIT)) {      // flag and saturate, like every other split encoder (kernels_elem.hip: split8)
+                                bad |= (fabsf(acc[v][cc * 16 + j]) <= 3.0e38f) ? RANGE_OVERFLOW : RANGE_NONFINITE;
+                                xs = fminf(fmaxf(xs, -F16_LIMIT), F16_LIMIT);
+                            }
                             _Float16 h = (_Float16)xs;
                             hi[j >> 3][j & 7] = h;
                             lo[j >> 3][j & 7] = (_Float16)(xs - (float)h);
@@ -1079,16 +1087,17 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ map
             if ((tid & 63) == 0) csum[tid >> 6][c * 32 + co] = sv;
         }
     }
+    if (bad && enc.err) atomicOr(enc.err, bad);
     __syncthreads();
     if (ws && tid < 128)
         ws[((int64_t)b * gridDim.x + blockIdx.x) * 128 + tid] = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
 }
 
 void launch_stem(const float* map, int B, Dims d, const float* wstem, const float* bstem, SplitView out,
-                 float* out_raw, float* gap, float* ws, float ascale, hipStream_t st) {
+                 float* out_raw, float* gap, float* ws, SplitEnc enc, hipStream_t st) {
     int ntx = (d.W + ST_X - 1) / ST_X, nty = (d.H + ST_Y - 1) / ST_Y, ntz = (d.D + ST_Z - 1) / ST_Z;
     dim3 grid(ntx * nty * ntz, B);
-    hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, st, map, d, wstem, bstem, out, out_raw, gap ? ws : nullptr, ntx, nty, ascale);
+    hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, st, map, d, wstem, bstem, out, out_raw, gap ? ws : nullptr, ntx, nty, enc);
     if (gap) launch_finalize_sum(ws, B, (int)grid.x, 128, 1.0f / (float)(d.D * d.H * d.W), gap, st);
 }
 

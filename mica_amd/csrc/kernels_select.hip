@@ -61,6 +61,18 @@ __global__ void finish_kernel(float* __restrict__ x, int64_t n, float med, float
     }
 }
 
+// Integer maps (MRC modes 0 / 1 / 6): numpy promotes them to float64 at `norm_data - median` (:124) and stays there until the
+// final astype(float32) (:139).  The map holds the integers as f32; differences against the median (an integer or a half) are
+// exact in either width, so only the clip / divide / final rounding need the wide type.
+__global__ void finish_f64_kernel(float* __restrict__ x, int64_t n, double med, double pct) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)x[i];
+        double m = (v > med) ? (v - med) : 0.0;
+        m = (m < pct) ? m : pct;
+        x[i] = (float)(m / pct);
+    }
+}
+
 namespace {
 struct Sel {
     const float* x; int64_t n; int mode; float med; unsigned* d_hist; hipStream_t st;
@@ -95,7 +107,8 @@ struct Sel {
 };
 }  // namespace
 
-int normalise_map_device(float* d_vol, int64_t n, double* h_stats, hipStream_t st, char* err, int errlen) {
+int normalise_map_device(float* d_vol, int64_t n, int kind, double* h_stats, hipStream_t st, char* err, int errlen) {
+    const bool wide = kind != MICA_MAP_F32;
     unsigned* d_hist = nullptr;
     if (hipMalloc((void**)&d_hist, 256 * sizeof(unsigned)) != hipSuccess) { snprintf(err, errlen, "normalise: hipMalloc failed"); return -2; }
     int rc = 0;
@@ -117,6 +130,26 @@ int normalise_map_device(float* d_vol, int64_t n, double* h_stats, hipStream_t s
         int r0 = p.run(0, &lo, &P);
         if (r0 < 0) { rc = -2; break; }
         if (P == 0) { snprintf(err, errlen, "No positive values found after thresholding"); rc = -3; break; }   // :163-165
+        if (wide) {
+            // np.median of an integer array is the float64 mean of the middle element(s): exact, and exact as the f32 above.
+            // np.percentile(pos, 99.9) on the float64 positives: the same 'linear' recipe in float64.
+            const double medd = (n & 1) ? (double)a : ((double)a + (double)b) / 2.0;
+            const double qd = 99.9 / 100.0;
+            const double vid = (double)(P - 1) * qd;
+            int64_t prevd = (int64_t)floor(vid), nextd = prevd + 1;
+            if (vid >= (double)(P - 1)) { prevd = P - 1; nextd = P - 1; }
+            const double gd = vid - floor(vid);
+            if (p.run(prevd, &lo, nullptr) || p.run(nextd, &hi, nullptr)) { rc = -2; break; }
+            const double dd = (double)hi - (double)lo;
+            double pctd = (double)lo + dd * gd;
+            if (gd >= 0.5) pctd = (double)hi - dd * (1.0 - gd);
+            if (pctd == 0.0) { snprintf(err, errlen, "Percentile value is zero - cannot normalize"); rc = -3; break; }
+            hipLaunchKernelGGL(finish_f64_kernel, dim3(2048), dim3(256), 0, st, d_vol, n, medd, pctd);
+            if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { rc = -2; break; }
+            h_stats[0] = medd;
+            h_stats[1] = pctd;
+            break;
+        }
         // np.percentile(pos, 99.9) for float32 input, numpy 2.x: everything in float32
         const float q = 99.9f / 100.0f;
         const float vi = (float)(P - 1) * q;

@@ -79,8 +79,24 @@ __device__ __forceinline__ bool axis_setup(const ZoomAxis& a, int o, int (&idx)[
     return true;
 }
 
+// scipy's conversion of the f64 result to an integer output array (the map keeps its MRC mode through zoom): add 0.5 away
+// from zero, clamp to the type's range, truncate (unsigned: negative -> 0).  The integers are stored as f32 (exact: 16 bits).
+__device__ __forceinline__ double round_like_scipy(double t, int kind) {
+    if (kind == MICA_MAP_F32) return t;
+    double lo, hi;
+    if (kind == MICA_MAP_U16) { t = t > 0.0 ? t + 0.5 : 0.0; lo = 0.0; hi = 65535.0; }
+    else {
+        t = t > 0.0 ? t + 0.5 : t - 0.5;
+        lo = kind == MICA_MAP_I8 ? -128.0 : -32768.0;
+        hi = kind == MICA_MAP_I8 ? 127.0 : 32767.0;
+    }
+    t = t > hi ? hi : t;
+    t = t < lo ? lo : t;
+    return trunc(t);
+}
+
 __global__ __launch_bounds__(256) void zoom_interp_kernel(const double* __restrict__ f, ZoomAxis a0, ZoomAxis a1, ZoomAxis a2,
-                                                          float* __restrict__ out) {
+                                                          int kind, float* __restrict__ out) {
     const int64_t total = (int64_t)a0.n_out * a1.n_out * a2.n_out;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -104,11 +120,11 @@ __global__ __launch_bounds__(256) void zoom_interp_kernel(const double* __restri
                 }
             }
     }
-    out[e] = (float)t;
+    out[e] = (float)round_like_scipy(t, kind);
 }
 
-int zoom_cubic_device(const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1, int64_t o2, float* d_out,
-                      hipStream_t st, char* err, int errlen) {
+int zoom_cubic_device(const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1, int64_t o2, int kind,
+                      float* d_out, hipStream_t st, char* err, int errlen) {
     const int64_t n = n0 * n1 * n2;
     double* f = nullptr;
     if (hipMalloc((void**)&f, (size_t)n * sizeof(double)) != hipSuccess) { snprintf(err, errlen, "zoom: hipMalloc(%lld B) failed", (long long)(n * 8)); return -2; }
@@ -140,7 +156,7 @@ int zoom_cubic_device(const float* d_in, int64_t n0, int64_t n1, int64_t n2, int
         a[k].zf = outs[k] > 1 ? (double)(ins[k] - 1) / (double)(outs[k] - 1) : 1.0;
     }
     const int64_t total = o0 * o1 * o2;
-    hipLaunchKernelGGL(zoom_interp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f, a[0], a[1], a[2], d_out);
+    hipLaunchKernelGGL(zoom_interp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f, a[0], a[1], a[2], kind, d_out);
     int rc = 0;
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { snprintf(err, errlen, "zoom: HIP failure"); rc = -2; }
     (void)hipFree(f);

@@ -99,11 +99,22 @@ def sharded_records(run_batch, stitch, T: int, batch: int, rec_shape, device, dt
     """run_batch(first, count) -> tensor [count, *rec_shape] on `device`;
     stitch(records [count, *rec_shape], first) is called on `stitch_rank` (None = every rank) for every
     batch of every rank, in global tile order within a round."""
-    ex = RecordExchange(batch, rec_shape, device, stitch, dtype=dtype, group=group, stitch_rank=stitch_rank)
-    mine, rounds = rank_batches(T, batch, ex.rank, ex.world)
     plan = batch_plan(T, batch)
+    seen = {}
+
+    def counted(rec, first):
+        seen[first] = seen.get(first, 0) + int(rec.shape[0])
+        stitch(rec, first)
+
+    ex = RecordExchange(batch, rec_shape, device, counted, dtype=dtype, group=group, stitch_rank=stitch_rank)
+    mine, rounds = rank_batches(T, batch, ex.rank, ex.world)
     for r, first, count in mine:
         layout = [plan[r * ex.world + rr] if r * ex.world + rr < len(plan) else (0, 0) for rr in range(ex.world)]
         ex.post(r, run_batch(first, count) if count else None, layout)
     ex.flush()
+    if stitch_rank is None or ex.rank == stitch_rank:
+        # every batch of the map reached the stitcher exactly once, whole (a dropped or repeated round would leave a hole in
+        # the volumes or overwrite a region silently)
+        if seen != dict(plan):
+            raise RuntimeError(f"sharded_records: stitched batches {sorted(seen.items())} != plan {plan}")
     return rounds

@@ -77,6 +77,17 @@ class Engine:
         self.weights_loaded = True
 
     # -- forward ----------------------------------------------------------------------------------
+    LOW_SCALE_WARN = 0.25      # below this the split encoding loses bits: the call still succeeds, loudly
+
+    def _check_forward(self, r, what):
+        self._check(r, what)
+        sc = float(self.lib.mica_get_last_forward_scale(self._h))
+        self.last_forward_scale = sc
+        if sc < self.LOW_SCALE_WARN:
+            import warnings
+            warnings.warn(f"{what}: activations of a tile exceeded {60000 / self.LOW_SCALE_WARN:.0f}; it was computed at activation "
+                          f"scale {sc} where the whole-network error can exceed 1e-4 (up to ~2e-4 measured)", RuntimeWarning, stacklevel=3)
+
     def _check_batch_mode(self, n: int, af, af_mode: int):
         """The batch-wide AF3 test (models/model.py:60) is a property of ONE forward call: a batch larger than the engine's
         max_batch would be cut into several calls and silently become a different test."""
@@ -99,7 +110,7 @@ class Engine:
         aa = torch.empty((B, 21, S, S, S), dtype=torch.float32, device=self.device)
         for b0 in range(0, B, self.max_batch):
             b1 = min(B, b0 + self.max_batch)
-            self._check(self.lib.mica_forward_logits(
+            self._check_forward(self.lib.mica_forward_logits(
                 self._h, _ptr(exp_map[b0:b1]), _ptr(af[b0:b1]) if af is not None else None, b1 - b0,
                 af_mode if af is not None else AF_NONE, _ptr(bb[b0:b1]), _ptr(ca[b0:b1]), _ptr(aa[b0:b1]), self._stream()),
                 "mica_forward_logits")
@@ -121,7 +132,7 @@ class Engine:
         bbp, cap, aap, pred = out
         for b0 in range(0, T, self.max_batch):
             b1 = min(T, b0 + self.max_batch)
-            self._check(self.lib.mica_forward_tiles(
+            self._check_forward(self.lib.mica_forward_tiles(
                 self._h, _ptr(map_tiles[b0:b1]), _ptr(af_tiles[b0:b1]) if af_tiles is not None else None, b1 - b0,
                 af_mode if af_tiles is not None else AF_NONE, _ptr(bbp[b0:b1]), _ptr(cap[b0:b1]), _ptr(aap[b0:b1]),
                 _ptr(pred[b0:b1]), self._stream()), "mica_forward_tiles")
@@ -140,7 +151,7 @@ class Engine:
             raise MicaHipError(f"rec must be a contiguous float32 CUDA(HIP) tensor [{T},23,{S},{S},{S}]")
         for b0 in range(0, T, self.max_batch):
             b1 = min(T, b0 + self.max_batch)
-            self._check(self.lib.mica_forward_records(
+            self._check_forward(self.lib.mica_forward_records(
                 self._h, _ptr(map_tiles[b0:b1]), _ptr(af_tiles[b0:b1]) if af_tiles is not None else None, b1 - b0,
                 af_mode if af_tiles is not None else AF_NONE, _ptr(rec[b0:b1]), self._stream()), "mica_forward_records")
         return rec
@@ -189,14 +200,16 @@ class Engine:
                                                _ptr(v4), self._stream()), "mica_stitch_tiles")
         return vol
 
-    def normalise_map_(self, vol: torch.Tensor):
-        """In place; returns (median, percentile).  Raises MicaHipError like the reference logs failure."""
+    def normalise_map_(self, vol: torch.Tensor, map_type: int = 0):
+        """In place; returns (median, percentile).  Raises MicaHipError like the reference logs failure.
+        map_type: MICA_MAP_* of include/mica_hip.h (0 float32 map; 1/2/3 = int8/int16/uint16 values held as f32)."""
         vol = _f32c(vol, "vol")
         st = (C.c_double * 2)()
-        self._check(self.lib.mica_normalise_map(self._h, _ptr(vol), vol.numel(), st, self._stream()), "mica_normalise_map")
+        self._check(self.lib.mica_normalise_map_typed(self._h, _ptr(vol), vol.numel(), int(map_type), st, self._stream()),
+                    "mica_normalise_map")
         return float(st[0]), float(st[1])
 
-    def zoom_cubic(self, vol: torch.Tensor, factors):
+    def zoom_cubic(self, vol: torch.Tensor, factors, map_type: int = 0):
         """scipy.ndimage.zoom(vol, factors, order=3) on the GPU (bit-exact); vol f32[N0,N1,N2] -> f32[round(N*f)]."""
         vol = _f32c(vol, "vol")
         n = tuple(vol.shape)
@@ -206,7 +219,8 @@ class Engine:
         if min(o) < 1:
             raise MicaHipError(f"zoom_cubic: empty output shape {o}")
         out = torch.empty(o, dtype=torch.float32, device=self.device)
-        self._check(self.lib.mica_zoom_cubic(self._h, _ptr(vol), *n, *o, _ptr(out), self._stream()), "mica_zoom_cubic")
+        self._check(self.lib.mica_zoom_cubic_typed(self._h, _ptr(vol), *n, *o, int(map_type), _ptr(out), self._stream()),
+                    "mica_zoom_cubic")
         return out
 
     def rasterise_atoms(self, xyz: torch.Tensor, bb: torch.Tensor, aa: torch.Tensor, origin, shape):
@@ -364,7 +378,8 @@ class Engine:
 
     @property
     def activation_scale(self) -> float:
-        """Scale of the split-f16 operand encoding: 16 unless an activation overflowed and the library stepped it down."""
+        """Scale of the split-f16 operand encoding every forward call starts from (16 unless set).  A tile that overflows is
+        repeated at a lower scale for that call only; `last_forward_scale` tells which."""
         return float(self.lib.mica_get_activation_scale(self._h))
 
     @activation_scale.setter

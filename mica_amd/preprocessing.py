@@ -19,6 +19,9 @@ from . import mrc
 from .engine import Engine, MicaHipError
 
 
+_MAP_TYPES = {np.dtype(np.float32): 0, np.dtype(np.int8): 1, np.dtype(np.int16): 2, np.dtype(np.uint16): 3}
+
+
 class DataPreprocessor:
     def __init__(self, map_path, AF3_results, quiet=False, engine: Engine | None = None, device=0):
         self.map_path = map_path
@@ -39,13 +42,17 @@ class DataPreprocessor:
         zf = [voxel_size[0] / target_voxel_size, voxel_size[1] / target_voxel_size, voxel_size[2] / target_voxel_size]
         eng = self._engine or Engine(self._device, max_batch=1, tile_size=64)
         self._engine = eng
-        if data.dtype != np.float32:
-            raise MicaHipError(f"map dtype {data.dtype}: the GPU resampler/normaliser takes float32 (MRC mode 2) maps")
-        t = torch.from_numpy(np.ascontiguousarray(data)).to(eng.device)
+        # the reference passes the array in the dtype mrcfile returns (:98-117): MRC modes 0/1/6 arrive as integers, stay
+        # integers through scipy's zoom and are promoted to float64 by numpy at :124 (include/mica_hip.h, MICA_MAP_*);
+        # mode 12 (float16) is refused by scipy.ndimage ("array type dtype('float16') not supported") and the reference fails
+        map_type = _MAP_TYPES.get(np.dtype(data.dtype))
+        if map_type is None:
+            raise MicaHipError(f"array type {np.dtype(data.dtype)!r} not supported")
+        t = torch.from_numpy(np.ascontiguousarray(data).astype(np.float32, copy=False)).to(eng.device)
         # the reference zooms unconditionally (:117); the kernel reproduces scipy bit for bit, including factor 1.0
         # (identity on finite data, NaN spreading through the recursive prefilter otherwise)
-        t = eng.zoom_cubic(t, zf)
-        med, pct = eng.normalise_map_(t)
+        t = eng.zoom_cubic(t, zf, map_type)
+        med, pct = eng.normalise_map_(t, map_type)
         return t.cpu().numpy(), med, pct
 
     def resample_and_normalize_map(self, target_voxel_size=1.0):

@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out_path, shape, batch = sys.argv[1], tuple(int(v) for v in sys.argv[2].split("x")), int(sys.argv[3])
+    grid, pad, seed = (int(v) for v in sys.argv[4:7]) if len(sys.argv) > 6 else (48, 8, 91)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -22,12 +23,20 @@ def main():
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     eng = Engine(0, max_batch=batch, tile_size=64)
     eng.load_state_dict(synth_state_dict(2022))
-    vol = torch.from_numpy(synth_density(shape, 91)).cuda()
-    af = torch.from_numpy(synth_af(shape, 91, 2e-3)).cuda()
+    vol = torch.from_numpy(synth_density(shape, seed)).cuda()
+    af = torch.from_numpy(synth_af(shape, seed, 2e-3)).cuda()
     af[:, :, :, : shape[2] // 2] = 0                       # some tiles see no atoms: per-tile gating on every rank
-    out = VolumePredictor(eng, 48, 8, batch).predict_volume_sharded(vol, af)
+    out = VolumePredictor(eng, grid, pad, batch).predict_volume_sharded(vol, af)
+    # coverage of the sharded stitch: all-one records through the same exchange fill a counter volume (no hole), and
+    # sharded_records itself raises unless every batch arrived exactly once
+    from mica_amd.dist import sharded_records
+    T = int(eng.lib.mica_tile_count(*shape, grid))
+    cover = torch.zeros((1, *shape), device="cuda")
+    ones = torch.ones((batch, 1, grid, grid, grid), device="cuda")
+    sharded_records(lambda first, count: ones[:count], lambda rec, first: eng.stitch_tiles(rec.contiguous(), cover, grid, 0, first),
+                    T, batch, (1, grid, grid, grid), torch.device("cuda"), stitch_rank=0)
     if dist.get_rank() == 0:
-        np.savez(out_path, **{k: v.cpu().numpy() for k, v in out.items()})
+        np.savez(out_path, coverage=cover[0].cpu().numpy(), **{k: v.cpu().numpy() for k, v in out.items()})
     else:
         assert out is None
     dist.barrier()
