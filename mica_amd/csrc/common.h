@@ -103,7 +103,7 @@ void launch_fill_float(float* p, int64_t n, float v, hipStream_t st);
 // depthwise 3^3 on raw input with fused (x-mean)*rstd, relu, *scale applied on load (zero padding after)
 // C must be a multiple of 16.  stats_ws (nullable): fused InstanceNorm partials, returns their count P.
 // gap_ws (nullable): f32 [B][P][C] per-block sums of the normalised input over the block's own voxels (launch_finalize_sum).
-int launch_depthwise(const float* x, int B, int Bplan, Dims d, int C, const float* mean, const float* rstd,
+int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st);
 // merge P partials f32 [B][P][C][3] = (count, mean, M2) into mean / rstd.  gate f32 [B][C] (nullable): the statistics are
 // those of u while the tensor that is normalised downstream is t = g u + const (g > 0 per tile and channel): then

@@ -351,7 +351,7 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         // DualAttention (model.py:98-101): local branch
         {
             prof_begin(c, 1, st);
-            const int P = launch_depthwise(c->R_b, B, c->maxB, d, C, c->v_mean3, c->v_rstd3, nullptr, E.dw_w, E.dw_b, c->R_c, c->ws, c->ws_gap, st);
+            const int P = launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, nullptr, E.dw_w, E.dw_b, c->R_c, c->ws, c->ws_gap, st);
             prof_end(c, 1, 8.0 * (double)C * V * B, st);     // algorithmic bytes: read + write 4 B per voxel and channel
             launch_finalize_sum(c->ws_gap, B, P, C, 1.0f / (float)V, c->v_pool, st);
             gate(c, E.se, c->v_pool, nullptr, B, nullptr, c->v_gse, nullptr, 0, st);      // SEBlock gate (model.py:254-258)
@@ -1097,7 +1097,7 @@ int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, 
     HIPC(c, hipMemcpy(dw, wt.data(), sizeof(float) * 27 * ch, hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(db, h_b, sizeof(float) * ch, hipMemcpyHostToDevice));
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
-    launch_depthwise(a, batch, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, nullptr, nullptr, st);
+    launch_depthwise(a, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, nullptr, nullptr, st);
     launch_nhwc_to_nchw(b, batch, ch, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));
@@ -1143,7 +1143,7 @@ int mica_op_se_depthwise(mica_ctx* c, const float* d_x, int batch, int ch, int d
     HIPC(c, hipMemsetAsync(derr, 0, 4, st));
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
     launch_stats(a, batch, V, ch, 1e-5f, m0, r0, ws, st);                                  // x3 = relu(IN(x)) is applied on load
-    const int P = launch_depthwise(a, batch, batch, dm, ch, m0, r0, nullptr, dw, db, u, ws, wsg, st);
+    const int P = launch_depthwise(a, batch, dm, ch, m0, r0, nullptr, dw, db, u, ws, wsg, st);
     launch_finalize_sum(wsg, batch, P, ch, 1.0f / (float)V, pool, st);                      // GAP(x3), summed by the depthwise kernel
     launch_gate_mlp(pool, nullptr, batch, ch, Ch, w1, b1, w2, b2, nullptr, gse, nullptr, 0, st);
     launch_stats_finalize(ws, batch, P, ch, 1e-5f, m1, r1, st, gse);                        // the SE gate folded into the norm constants

@@ -948,11 +948,13 @@ static void launch_depthwise_t(const float* x, int B, Dims d, int C, const float
     dim3 grid((unsigned)(ntx * nty * (C / Gm::DWC)), B);
     hipLaunchKernelGGL((depthwise_kernel<YO, CQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty);
 }
-int launch_depthwise(const float* x, int B, int Bplan, Dims d, int C, const float* mean, const float* rstd,
+int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st) {
     const int ntx = (d.W + DW_X - 1) / DW_X;
-    // The variant fixes the number and order of the statistics / pool partials of a tile, so it is chosen from the context's
-    // batch capacity (Bplan), never from the size of this call: a tile's numbers do not depend on how many tiles share its call.
+    // The variant fixes the number and order of the statistics / pool partials of a tile, so it is chosen from the tile geometry
+    // (C, H, W) alone - as if 8 tiles were in flight, the throughput case - never from the size of this call or the capacity of
+    // the context: a tile's numbers do not depend on how many tiles share its call, nor on which engine computed them.
+    constexpr int Bplan = 8;
     // 32-channel workgroups (full 128-B lines) when that still gives every CU at least two rounds of work
     if (C % 32 == 0 && (int64_t)ntx * ((d.H + 15) / 16) * (C / 32) * Bplan >= 256) {
         const int nty = (d.H + 15) / 16;

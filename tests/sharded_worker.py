@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 def main():
     out_path, shape, batch = sys.argv[1], tuple(int(v) for v in sys.argv[2].split("x")), int(sys.argv[3])
     grid, pad, seed = (int(v) for v in sys.argv[4:7]) if len(sys.argv) > 6 else (48, 8, 91)
+    zero_x = int(sys.argv[7]) if len(sys.argv) > 7 else -1
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -25,7 +26,10 @@ def main():
     eng.load_state_dict(synth_state_dict(2022))
     vol = torch.from_numpy(synth_density(shape, seed)).cuda()
     af = torch.from_numpy(synth_af(shape, seed, 2e-3)).cuda()
-    af[:, :, :, : shape[2] // 2] = 0                       # some tiles see no atoms: per-tile gating on every rank
+    if zero_x >= 0:
+        af[:, :zero_x] = 0                                 # windows that end before x = zero_x see no atoms
+    else:
+        af[:, :, :, : shape[2] // 2] = 0                   # some tiles see no atoms: per-tile gating on every rank
     out = VolumePredictor(eng, grid, pad, batch).predict_volume_sharded(vol, af)
     # coverage of the sharded stitch: all-one records through the same exchange fill a counter volume (no hole), and
     # sharded_records itself raises unless every batch arrived exactly once
