@@ -47,6 +47,7 @@ SIGNATURES = {
     "mica_segment_sums": (_I, [_P, _P, _P, _L, _P, _P]),
     "mica_nms_points": (_I, [_P, _P, _L, _L, _L, _L, C.c_double, _P, _P]),
     "mica_neighbour_matrix": (_I, [_P, _P, _L, _P, _L, _L, _L, _P, _P, _P]),
+    "mica_neighbour_matrix_np": (_I, [_P, _P, _L, _P, _L, _L, _L, _I, _P, _P, _P]),
     "mica_op_conv3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _I, _P, _P]),
     "mica_op_norm_conv1_conv3": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _FP, _FP, _I, _P, _P]),
     "mica_op_instnorm_relu": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),

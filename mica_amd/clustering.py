@@ -97,12 +97,13 @@ def nms(engine, ca_at_points, pts, val_mat, vol_shape, thr: float, nms_radius: f
     return p[:n][keep].astype(np.int64)
 
 
-def neighbours(engine, volumes: dict, ca_cands):
+def neighbours(engine, volumes: dict, ca_cands, numpy_legacy: bool = False):
     """modeler.py:860-888.  ca_cands float64 [n,3] (refined positions).  -> (cand_self_dis, (neighbors2to6, neighbors0to6,
-    neighbors0to7, neighbors2to7), neigh_mat) as host arrays / lists of index arrays."""
+    neighbors0to7, neighbors2to7), neigh_mat) as host arrays / lists of index arrays.  numpy_legacy=True reproduces the
+    reference's pinned numpy 1.19.1 (float64 density sums) instead of numpy 2's NEP 50 promotion."""
     bb = volumes["backbone_probability"]
     c = torch.as_tensor(np.ascontiguousarray(ca_cands, dtype=np.float64).reshape(-1, 3)).to(bb.device)
-    dis, mat = engine.neighbour_matrix(c, bb)
+    dis, mat = engine.neighbour_matrix(c, bb, numpy_legacy)
     dis, mat = dis.cpu().numpy(), mat.cpu().numpy()
     n = dis.shape[0]
     lists = ([np.where((dis[i] <= 6) * (dis[i] >= 2))[0] for i in range(n)], [np.where(dis[i] <= 6)[0] for i in range(n)],

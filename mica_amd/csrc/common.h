@@ -165,6 +165,6 @@ int refine_candidates_device(const float* d_ca, const float* d_aa, int n0, int n
 int segment_sums_device(const float* d_vals, const int64_t* d_seg_off, int64_t nseg, float* d_sums, hipStream_t st, char* err, int errlen);
 int nms_points_device(const int* d_pts, int64_t n, int n0, int n1, int n2, double radius, int* d_keep, hipStream_t st, char* err, int errlen);
 int neighbour_matrix_device(const double* d_cands, int64_t n, const float* d_bb, int n0, int n1, int n2, double* d_dis, double* d_mat,
-                            hipStream_t st, char* err, int errlen);
+                            int legacy, hipStream_t st, char* err, int errlen);
 
 }  // namespace mica

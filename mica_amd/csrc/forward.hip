@@ -930,14 +930,19 @@ int mica_nms_points(mica_ctx* c, const int32_t* d_pts, int64_t n, int64_t n0, in
 
 int mica_neighbour_matrix(mica_ctx* c, const double* d_cands, int64_t n, const float* d_bb, int64_t n0, int64_t n1, int64_t n2,
                           double* d_dis, double* d_mat, void* stream) {
+    return mica_neighbour_matrix_np(c, d_cands, n, d_bb, n0, n1, n2, MICA_NUMPY_NEP50, d_dis, d_mat, stream);
+}
+
+int mica_neighbour_matrix_np(mica_ctx* c, const double* d_cands, int64_t n, const float* d_bb, int64_t n0, int64_t n1, int64_t n2,
+                             int numpy_rules, double* d_dis, double* d_mat, void* stream) {
     if (!c) return MICA_ERR_ARG;
-    if (n < 0 || n > 65535 || n0 < 1 || n1 < 1 || n2 < 1 || n0 > 4096 || n1 > 4096 || n2 > 4096 || (n > 0 && (!d_cands || !d_bb || !d_dis || !d_mat))) {
+    if ((numpy_rules != MICA_NUMPY_NEP50 && numpy_rules != MICA_NUMPY_LEGACY) || n < 0 || n > 65535 || n0 < 1 || n1 < 1 || n2 < 1 || n0 > 4096 || n1 > 4096 || n2 > 4096 || (n > 0 && (!d_cands || !d_bb || !d_dis || !d_mat))) {
         c->err = "mica_neighbour_matrix: bad argument";
         return MICA_ERR_ARG;
     }
     HIPC(c, hipSetDevice(c->device));
     char buf[256] = {0};
-    int r = neighbour_matrix_device(d_cands, n, d_bb, (int)n0, (int)n1, (int)n2, d_dis, d_mat, (hipStream_t)stream, buf, sizeof(buf));
+    int r = neighbour_matrix_device(d_cands, n, d_bb, (int)n0, (int)n1, (int)n2, d_dis, d_mat, numpy_rules, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
     return r;
 }

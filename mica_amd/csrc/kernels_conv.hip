@@ -783,37 +783,52 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
     float4 nm = make_float4(0, 0, 0, 0), nr = make_float4(1, 1, 1, 1), ns = make_float4(1, 1, 1, 1);
     if (mean) { nm = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c0 + lq * 4); nr = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c0 + lq * 4); }
     if (scale) ns = *reinterpret_cast<const float4*>(scale + (int64_t)b * C + c0 + lq * 4);
-    auto fetch_plane = [&](int gz, float4 (&pre)[NE]) {
+    // Everything about a thread's NE plane elements that does not depend on z is worked out once: the float offset of the
+    // (clamped) voxel inside a z plane, whether the element lies inside the volume / the plane image / the block's own voxels.
+    // (The per-plane versions of these index computations were ~1200 VALU cycles per plane and wave - a sixth of the kernel.)
+    int goff[NE];
+    unsigned okm = 0, inm = 0, valm = 0;
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            const int e = tid + NT * k;
-            const int v = e / CQ;
-            const int lx = v % DW_LX, ly = v / DW_LX;
-            const int cx = min(max(x0 + lx - 1, 0), d.W - 1), cy = min(max(y0 + ly - 1, 0), d.H - 1), cz = min(max(gz, 0), d.D - 1);
-            pre[k] = *reinterpret_cast<const float4*>(x + ((int64_t)b * V + (int64_t)(cz * d.H + cy) * d.W + cx) * C + c0 + lq * 4);
-        }
+    for (int k = 0; k < NE; ++k) {
+        const int e = tid + NT * k;
+        const int v = e / CQ;
+        const int lx = v % DW_LX, ly = v / DW_LX;
+        const int cx = min(max(x0 + lx - 1, 0), d.W - 1), cy = min(max(y0 + ly - 1, 0), d.H - 1);
+        goff[k] = (cy * d.W + cx) * C + c0 + lq * 4;
+        const bool val = e < DW_LX * DW_LY * CQ;
+        if ((unsigned)(x0 + lx - 1) < (unsigned)d.W && (unsigned)(y0 + ly - 1) < (unsigned)d.H) okm |= 1u << k;
+        if (val) valm |= 1u << k;
+        if (val && lx >= 1 && lx <= DW_X && ly >= 1 && ly <= DW_Y) inm |= 1u << k;
+    }
+    const float* xb = x + (int64_t)b * V * C;
+    const int64_t zstride = (int64_t)d.H * d.W * C;
+    auto fetch_plane = [&](int gz, float4 (&pre)[NE]) {
+        const float* pz = xb + (int64_t)min(max(gz, 0), d.D - 1) * zstride;
+#pragma unroll
+#ifdef MICA_DW_NOFETCH
+        for (int k = 0; k < NE; ++k) pre[k] = make_float4(1.f, 2.f, 3.f, (float)gz);       // ablation: no HBM reads
+        (void)pz;
+#else
+        for (int k = 0; k < NE; ++k) pre[k] = *reinterpret_cast<const float4*>(pz + goff[k]);
+#endif
     };
     // gap_ws: the global average pool of the NORMALISED input (the SE gate's input, model.py:256) rides along: every voxel is an
     // interior element of exactly one block
     float4 gsum = make_float4(0, 0, 0, 0);
     auto store_plane = [&](int slot, int gz, float4 (&pre)[NE]) {
-        float* dst = ring + slot * DW_PLANE;
-        const bool zok = (unsigned)gz < (unsigned)d.D;
+        float* dst = ring + slot * DW_PLANE + tid * 4;              // element e = v * CQ + lq sits at float e * 4
+        const unsigned zm = (unsigned)gz < (unsigned)d.D ? okm : 0u;
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const int e = tid + NT * k;
-            const int v = e / CQ;
-            const int lx = v % DW_LX, ly = v / DW_LX;
-            const bool ok = zok && (unsigned)(x0 + lx - 1) < (unsigned)d.W && (unsigned)(y0 + ly - 1) < (unsigned)d.H;
             float4 t = pre[k];
             if (mean) {
                 t.x = fmaxf((t.x - nm.x) * nr.x, 0.f) * ns.x; t.y = fmaxf((t.y - nm.y) * nr.y, 0.f) * ns.y;
                 t.z = fmaxf((t.z - nm.z) * nr.z, 0.f) * ns.z; t.w = fmaxf((t.w - nm.w) * nr.w, 0.f) * ns.w;
             } else { t.x *= ns.x; t.y *= ns.y; t.z *= ns.z; t.w *= ns.w; }
-            if (!ok) t = make_float4(0, 0, 0, 0);
-            if (e < DW_LX * DW_LY * CQ) {
-                *reinterpret_cast<float4*>(dst + v * DW_C + lq * 4) = t;
-                if (lx >= 1 && lx <= DW_X && ly >= 1 && ly <= DW_Y) { gsum.x += t.x; gsum.y += t.y; gsum.z += t.z; gsum.w += t.w; }
+            if (!(zm >> k & 1u)) t = make_float4(0, 0, 0, 0);
+            if (valm >> k & 1u) {
+                *reinterpret_cast<float4*>(dst + NT * 4 * k) = t;
+                if (inm >> k & 1u) { gsum.x += t.x; gsum.y += t.y; gsum.z += t.z; gsum.w += t.w; }
             }
         }
     };
@@ -824,6 +839,9 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
         float4 acc[YO];
 #pragma unroll
         for (int i = 0; i < YO; ++i) acc[i] = bv;
+#ifdef MICA_DW_NOCOMPUTE
+        if (z < 0)          // ablation: no taps (the outputs are the bias)
+#endif
 #pragma unroll 1
         for (int dz = 0; dz < 3; ++dz) {
             const float* pl = ring + ((z + dz) % 3) * DW_PLANE + (xi * DW_C + cq * 4);
@@ -858,31 +876,44 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
             }
         }
     };
+#ifdef MICA_DW_CLOCKS
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    const long long t_entry = __builtin_readcyclecounter();
+#define DWCLK(i, stmt) do { const long long t0_ = __builtin_readcyclecounter(); stmt; tk[i] += __builtin_readcyclecounter() - t0_; } while (0)
+#else
+#define DWCLK(i, stmt) do { stmt; } while (0)
+#endif
     fetch_plane(-1, preA); fetch_plane(0, preB); fetch_plane(1, preC);
     store_plane(0, -1, preA); store_plane(1, 0, preB); store_plane(2, 1, preC);
     fetch_plane(2, preA); fetch_plane(3, preB);
     __syncthreads();
+#ifdef MICA_DW_CLOCKS
+    const long long t_loop = __builtin_readcyclecounter();
+#endif
     // invariant at the top of an iteration z (multiple of 3): preA holds plane z + 2 and preB plane z + 3 (in flight), the
     // ring holds z-1, z, z+1
     for (int z = 0; z < d.D; z += 3) {
-        fetch_plane(z + 4, preC);
-        compute_plane(z);
-        __syncthreads();                    // plane z-1 (slot z % 3) is no longer read by anyone
-        store_plane(z % 3, z + 2, preA);    // plane z+2 takes its place
-        __syncthreads();
+        DWCLK(0, fetch_plane(z + 4, preC));
+        DWCLK(1, compute_plane(z));
+        DWCLK(2, __syncthreads());                    // plane z-1 (slot z % 3) is no longer read by anyone
+        DWCLK(3, store_plane(z % 3, z + 2, preA));    // plane z+2 takes its place
+        DWCLK(4, __syncthreads());
         if (z + 1 >= d.D) break;
-        fetch_plane(z + 5, preA);
-        compute_plane(z + 1);
-        __syncthreads();
-        store_plane((z + 1) % 3, z + 3, preB);
-        __syncthreads();
+        DWCLK(0, fetch_plane(z + 5, preA));
+        DWCLK(1, compute_plane(z + 1));
+        DWCLK(2, __syncthreads());
+        DWCLK(3, store_plane((z + 1) % 3, z + 3, preB));
+        DWCLK(4, __syncthreads());
         if (z + 2 >= d.D) break;
-        fetch_plane(z + 6, preB);
-        compute_plane(z + 2);
-        __syncthreads();
-        store_plane((z + 2) % 3, z + 4, preC);
-        __syncthreads();
+        DWCLK(0, fetch_plane(z + 6, preB));
+        DWCLK(1, compute_plane(z + 2));
+        DWCLK(2, __syncthreads());
+        DWCLK(3, store_plane((z + 2) % 3, z + 4, preC));
+        DWCLK(4, __syncthreads());
     }
+#ifdef MICA_DW_CLOCKS
+    const long long t_done = __builtin_readcyclecounter();
+#endif
     if (gap_ws) {
         // block sum per channel: the 64 threads that share a channel quad, fixed tree
         __syncthreads();
@@ -934,6 +965,12 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
 #pragma unroll
         for (int j = 0; j < 4; ++j) { wsp[j * 3] = shn[tid * 4 + j]; wsp[j * 3 + 1] = shm[tid * 4 + j]; wsp[j * 3 + 2] = shq[tid * 4 + j]; }
     }
+#ifdef MICA_DW_CLOCKS
+    if ((tid & 63) == 0 && (tid >> 6) % 4 == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 77))
+        printf("dw<%d,%d> C=%d blk %d wave %d: prologue %lld loop %lld epilogue %lld | per plane: fetch %lld compute %lld barA %lld store %lld barB %lld\n", YO, CQ, C,
+               (int)blockIdx.x, tid >> 6, t_loop - t_entry, t_done - t_loop, (long long)__builtin_readcyclecounter() - t_done, tk[0] / d.D, tk[1] / d.D,
+               tk[2] / d.D, tk[3] / d.D, tk[4] / d.D);
+#endif
 }
 
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null).

@@ -382,9 +382,11 @@ int nms_points_device(const int* d_pts, int64_t n, int n0, int n1, int n2, doubl
 //   Python's max(0, x) returns the int 0 unless x > 0, so the type of dis_score decides where the last sum is formed
 //   (NEP 50): a float64 distance term -> float64 sum; a Python number (dis = 0 -> dis_score = 1.0, or dis_score = 0) ->
 //   float32 sum.  Both are reproduced.
+// legacy = 1: numpy 1.x value-based promotion, the reference's own environment (environment.yml pins numpy 1.19.1): `0 + np.float32`
+//   is a float64 there, so BB_dens, BB_dens/4 and the final sum are all float64 (float64 adds of the float32 samples).
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ void neighbour_matrix_kernel(const double* __restrict__ cands, int64_t n, const float* __restrict__ bb, int n0, int n1, int n2,
-                                        double* __restrict__ dis, double* __restrict__ mat, int* __restrict__ flag) {
+                                        double* __restrict__ dis, double* __restrict__ mat, int* __restrict__ flag, int legacy) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * n) return;
     const int64_t i = e / n, j = e - i * n;             // i = cand, j = neigh
@@ -397,6 +399,7 @@ __global__ void neighbour_matrix_kernel(const double* __restrict__ cands, int64_
     double out = 0.0;
     if (d <= 6.0 && d >= 2.0) {
         float dens = 0.f;                                // BB_dens = 0; 0 + float32 is a float32 add
+        double dens64 = 0.0;                             // ... and a float64 add under numpy 1.x
         for (int q = 1; q <= 4; ++q) {
             const double wa = (double)q / 5.0, wb = (double)(5 - q) / 5.0;
             int64_t c[3];
@@ -406,10 +409,14 @@ __global__ void neighbour_matrix_kernel(const double* __restrict__ cands, int64_
             if (c[0] < 0 || c[0] >= n0 || c[1] < 0 || c[1] >= n1 || c[2] < 0 || c[2] >= n2) { atomicOr(flag, 1); c[0] = c[1] = c[2] = 0; }
             const float v = bb[(c[0] * n1 + c[1]) * n2 + c[2]];
             dens = __fadd_rn(dens, v);
+            dens64 = __dadd_rn(dens64, (double)v);
         }
         const float q4 = __fdiv_rn(dens, 4.0f);
         const double t = __dsub_rn(fabs(__dsub_rn(d, 3.8)), 0.5);
-        if (!(t > 0.0)) {
+        if (legacy) {
+            const double ds = (t > 0.0) ? __dsub_rn(1.0, __ddiv_rn(t, 2.0)) : 1.0;      // max(0, .) picks the int 0 unless x > 0
+            out = __ddiv_rn(__dadd_rn(ds > 0.0 ? ds : 0.0, __ddiv_rn(dens64, 4.0)), 2.0);
+        } else if (!(t > 0.0)) {
             out = (double)__fdiv_rn(__fadd_rn(1.0f, q4), 2.0f);           // dis = 0 (int): dis_score = 1.0 (Python float) -> float32 sum
         } else {
             const double ds = __dsub_rn(1.0, __ddiv_rn(t, 2.0));
@@ -421,14 +428,14 @@ __global__ void neighbour_matrix_kernel(const double* __restrict__ cands, int64_
 }
 
 int neighbour_matrix_device(const double* d_cands, int64_t n, const float* d_bb, int n0, int n1, int n2, double* d_dis, double* d_mat,
-                            hipStream_t st, char* err, int errlen) {
+                            int legacy, hipStream_t st, char* err, int errlen) {
     if (n == 0) return 0;
     int* d_flag = nullptr;
     int h_flag = 0;
     if (hipMalloc(&d_flag, sizeof(int)) != hipSuccess) { snprintf(err, errlen, "mica_neighbour_matrix: hipMalloc failed"); return -2; }
     hipMemsetAsync(d_flag, 0, sizeof(int), st);
     hipLaunchKernelGGL(neighbour_matrix_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, d_cands, n, d_bb, n0, n1, n2, d_dis, d_mat,
-                       d_flag);
+                       d_flag, legacy);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -304,8 +304,9 @@ class Engine:
                     "mica_nms_points")
         return keep.bool()
 
-    def neighbour_matrix(self, cands: torch.Tensor, bb: torch.Tensor):
-        """modeler.py:860-888: cands f64[n,3], bb f32[N0,N1,N2] -> (cand_self_dis f64[n,n], neigh_mat f64[n,n]) on the device."""
+    def neighbour_matrix(self, cands: torch.Tensor, bb: torch.Tensor, numpy_legacy: bool = False):
+        """modeler.py:860-888: cands f64[n,3], bb f32[N0,N1,N2] -> (cand_self_dis f64[n,n], neigh_mat f64[n,n]) on the device.
+        numpy_legacy: the promotion rules of numpy 1.x (the reference's pinned 1.19.1: float64 density sums) instead of numpy 2."""
         bb = _f32c(bb, "bb")
         if cands.dtype != torch.float64 or not cands.is_cuda or cands.dim() != 2 or cands.shape[1] != 3:
             raise MicaHipError("cands: expected a float64 CUDA(HIP) tensor [n,3]")
@@ -313,8 +314,8 @@ class Engine:
         n = cands.shape[0]
         dis = torch.empty((n, n), dtype=torch.float64, device=self.device)
         mat = torch.empty((n, n), dtype=torch.float64, device=self.device)
-        self._check(self.lib.mica_neighbour_matrix(self._h, _ptr(cands), n, _ptr(bb), *bb.shape, _ptr(dis), _ptr(mat), self._stream()),
-                    "mica_neighbour_matrix")
+        self._check(self.lib.mica_neighbour_matrix_np(self._h, _ptr(cands), n, _ptr(bb), *bb.shape, int(bool(numpy_legacy)), _ptr(dis),
+                                                      _ptr(mat), self._stream()), "mica_neighbour_matrix")
         return dis, mat
 
     # -- single ops (tests) -----------------------------------------------------------------------------

@@ -40,6 +40,7 @@ class CryoEMPredictor:
         self.batch_size = batch_size
         self.reference_batching = bool(reference_batching)
         self.batch_threshold = 200          # utils/predict.py:72 (an instance attribute there too)
+        self.loader_threads = max(2, min(12, (os.cpu_count() or 8) - 2))      # tile-file readers beside the GPU
         self.use_optimized_batching = False
         self.optimal_batch_size = 1
         self.engine = None
@@ -127,18 +128,29 @@ class CryoEMPredictor:
                     for q, t in enumerate(grp):
                         e.stitch_tiles(rec[q:q + 1], out, grid, pad, tindex(t))
                 pos = len(order)
+            # runs of consecutive tiles; their files are read on a small thread pool a few runs ahead of the GPU (25 .npz files
+            # = 26 MB per tile: the reference's DataLoader reads them on the main thread between forwards, predict.py:70,334)
+            runs = []
             while pos < len(order):
                 run = [order[pos]]
                 while len(run) < B and pos + len(run) < len(order) and tindex(order[pos + len(run)]) == tindex(run[-1]) + 1:
                     run.append(order[pos + len(run)])
-                items = [dataset[t] for t in run]
-                x = torch.from_numpy(np.stack([it[0] for it in items])).to(e.device)
-                afh = np.stack([it[1] for it in items])
-                af = torch.from_numpy(afh).to(e.device) if np.any(afh) else None
-                n = len(run)
-                e.forward_records(x.view(n, S, S, S), af, rec[:n], af_mode=AF_PER_TILE)
-                e.stitch_tiles(rec[:n], out, grid, pad, tindex(run[0]))
-                pos += n
+                runs.append(run)
+                pos += len(run)
+            from concurrent.futures import ThreadPoolExecutor
+            ahead = 3
+            with ThreadPoolExecutor(max_workers=self.loader_threads) as pool:
+                pending = [[pool.submit(dataset.__getitem__, t) for t in run] for run in runs[:ahead]]
+                for r, run in enumerate(runs):
+                    items = [f.result() for f in pending.pop(0)]
+                    if r + ahead < len(runs):
+                        pending.append([pool.submit(dataset.__getitem__, t) for t in runs[r + ahead]])
+                    x = torch.from_numpy(np.stack([it[0] for it in items])).to(e.device)
+                    afh = np.stack([it[1] for it in items])
+                    af = torch.from_numpy(afh).to(e.device) if np.any(afh) else None
+                    n = len(run)
+                    e.forward_records(x.view(n, S, S, S), af, rec[:n], af_mode=AF_PER_TILE)
+                    e.stitch_tiles(rec[:n], out, grid, pad, tindex(run[0]))
             vols = {"backbone_probability": out[0].cpu().numpy(), "carbon_alpha_probability": out[1].cpu().numpy(),
                     "amino_acid_prediction": out[2].cpu().numpy(), "amino_acid_probability": out[3:].cpu().numpy()}
             self.timing_stats['inference'] = time.time() - t0

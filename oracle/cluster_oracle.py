@@ -112,11 +112,12 @@ def calc_dis(coordList1, coordList2):
     return a
 
 
-def neighbour_matrix(ca_cands, bb_prob):
+def neighbour_matrix(ca_cands, bb_prob, numpy_legacy=False):
     """:860-888.  ca_cands float64 [n,3] (the refined positions).  Returns (cand_self_dis, the four neighbour lists,
     neigh_mat).  NOTE (parity): evaluated with the numpy of this container (2.x, NEP 50): BB_dens accumulates in float32
     and, where the distance term is a Python number, the final sum is formed in float32; under the reference's pinned
-    numpy 1.19 the same statements promote to float64."""
+    numpy 1.19 the same statements promote to float64 (value-based casting: Python int + np.float32 -> float64), which
+    numpy_legacy=True states explicitly (np.float64 operands) so that it needs no old numpy."""
     cand_self_dis = calc_dis(ca_cands, ca_cands)
     n = ca_cands.shape[0]
     neighbors2to6, neighbors0to6, neighbors0to7, neighbors2to7 = [], [], [], []
@@ -131,11 +132,11 @@ def neighbour_matrix(ca_cands, bb_prob):
     neigh_mat = np.zeros_like(cand_self_dis)
     for cand in range(n):
         for neigh in neighbors2to6[cand]:
-            BB_dens = 0
+            BB_dens = np.float64(0) if numpy_legacy else 0
             dis = max(0, abs(cand_self_dis[cand, neigh] - 3.8) - 0.5)
             dis_score = max(0, 1 - dis / 2)
             for j in range(1, 5):
                 coord = np.round(j/5 * ca_cands[neigh] + (5-j)/5 * ca_cands[cand]).astype(int)
-                BB_dens += bb_prob[coord[0], coord[1], coord[2]]
+                BB_dens += np.float64(bb_prob[coord[0], coord[1], coord[2]]) if numpy_legacy else bb_prob[coord[0], coord[1], coord[2]]
             neigh_mat[cand, neigh] = (dis_score + BB_dens/4) / 2
     return cand_self_dis, (neighbors2to6, neighbors0to6, neighbors0to7, neighbors2to7), neigh_mat

@@ -486,6 +486,10 @@ def test_cluster_scores_nms_and_neighbour_matrix_bit_exact(eng):
     # both promotion branches of the last sum occur: distance term zero (3.3 <= dis <= 4.3) and non-zero
     inband = (rdis >= 2) & (rdis <= 6)
     assert ((np.abs(rdis - 3.8) <= 0.5) & inband).any() and ((np.abs(rdis - 3.8) > 0.5) & inband).any()
+    # the reference's own environment (numpy 1.19.1): float64 density sums, stated explicitly in the oracle
+    _, _, rmat1 = co.neighbour_matrix(rc, bb, numpy_legacy=True)
+    _, _, gmat1 = cl.neighbours(eng, vols, new_c, numpy_legacy=True)
+    assert np.array_equal(gmat1, rmat1) and not np.array_equal(rmat1, rmat) and np.abs(rmat1 - rmat).max() < 1e-6
 
 
 @pytest.mark.parametrize("n,radius,seed", [(6000, 9, 1), (6000, 2.5, 2), (300, 30, 3), (1, 9, 4)])
