@@ -27,6 +27,33 @@ struct SplitEnc {           // where the split encoders report and how they scal
 };
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// The split encoder every operand producer uses: x * ascale = hi + lo in f16.  Values beyond the f16 range are flagged and
+// SATURATED (an overflow must not turn into Inf/NaN downstream: the caller repeats the tile at a lower scale, forward.hip).
+// The range test is one v_med3 + one compare into a scalar mask per value; which kind of violation it was is worked out on a
+// wave-uniform slow path that only runs when some lane saw one (the per-value flag logic used to be a third of the encoder's
+// VALU work, and the 1x1 kernels are VALU-bound on exactly this).
+__device__ __forceinline__ void mica_split8(const float (&y)[8], half8& hi, half8& lo, int& bad, float ascale) {
+    float c[8];
+    unsigned long long viol = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xs = y[j] * ascale;
+        c[j] = __builtin_amdgcn_fmed3f(xs, -F16_LIMIT, F16_LIMIT);      // NaN -> -F16_LIMIT (v_med3 returns the minimum when an input is NaN)
+        viol |= __builtin_amdgcn_ballot_w64(c[j] != xs);
+    }
+    if (viol) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (!(fabsf(y[j] * ascale) <= F16_LIMIT)) bad |= (fabsf(y[j]) <= 3.0e38f) ? RANGE_OVERFLOW : RANGE_NONFINITE;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)c[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(c[j] - (float)h);
+    }
+}
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 

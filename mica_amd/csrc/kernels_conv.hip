@@ -86,6 +86,23 @@ typedef float floatx4v __attribute__((ext_vector_type(4)));
 #else
 #define MICA_EXP_EPI_PASSES(n) (n)
 #endif
+// energy ablations (timing experiments only, results are garbage): -DMICA_EXP_SLAB_FIXED wraps every slab DMA into the first 4 MB of
+// the operand (the data stay random - a constant slab would lower the MFMA power by itself - but come from L2: no HBM traffic for
+// the operand, the LDS-DMA writes remain); -DMICA_EXP_W_FIXED makes every weight fragment load hit the same 4 KB per wave (L1 hits
+// instead of the L2 stream).  Measured on single layers with random inputs (tools/exp/abl.sh): inside the network an ablated conv
+// feeds garbage to the next one and changes ITS power.
+#ifdef MICA_EXP_SLAB_FIXED
+#define MICA_EXP_SLABOFF(x) ((x) & 0x3FFFF0)      /* wrapped into the first 4 MB of the operand: random data, served by L2 */
+#define MICA_EXP_SLABBASE(b) (s.p[0])
+#else
+#define MICA_EXP_SLABOFF(x) (x)
+#define MICA_EXP_SLABBASE(b) (b)
+#endif
+#ifdef MICA_EXP_W_FIXED
+#define MICA_EXP_WBASE(b) (wwave)
+#else
+#define MICA_EXP_WBASE(b) (b)
+#endif
 #ifndef MICA_BLOCKED_WALK
 #define MICA_BLOCKED_WALK 1
 #endif
@@ -187,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 #define W16_SEL(ls, M) ((SPLIT && wsel == 1) ? M((ls) + 7) : M(ls))
 #define MICA_BLOAD16(set, wbase, ls)                                                                                    \
     do {                                                                                                                \
-        const char* pb_ = (wbase) + W16_SEL(ls, W16_WOFF);                                                              \
+        const char* pb_ = MICA_EXP_WBASE(wbase) + W16_SEL(ls, W16_WOFF);                                                \
         const unsigned vo_ = w_common + (unsigned)(W16_SEL(ls, W16_WDELTA) & himask);                                   \
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][0]) : "v"(vo_), "s"(pb_) : "memory");              \
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(bq[set][1]) : "v"(vo_), "s"(pb_) : "memory");   \
@@ -206,11 +223,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
         const unsigned la_ = __builtin_amdgcn_readfirstlane(lds0 + lo_);                                                \
         const bool ok_ = (org).i0 + (lane & 7) < Wh && (unsigned)((org).y0 + (rel[k] & 7)) < (unsigned)d.H &&           \
                          (unsigned)((org).z0 + w16_slab_vz(wave, k)) < (unsigned)d.D;                                   \
-        const int go_ = ok_ ? (org).base + (rel[k] & ~15) : -1;                                                         \
+        const int go_ = ok_ ? MICA_EXP_SLABOFF((org).base + (rel[k] & ~15)) : -1;                                       \
         unsigned long long sv_;                                                                                         \
         asm volatile("s_mov_b64 %0, exec\n\tv_cmp_lt_i32 vcc, -1, %1\n\ts_mov_b64 exec, vcc\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" \
                      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                                              \
-                     : "=&s"(sv_) : "v"(go_), "s"(srcbase), "s"(la_) : "memory", "vcc", "m0");                           \
+                     : "=&s"(sv_) : "v"(go_), "s"(MICA_EXP_SLABBASE(srcbase)), "s"(la_) : "memory", "vcc", "m0");        \
         if (!ok_) *reinterpret_cast<uint4*>(smem + lo_ + lane * 16) = make_uint4(0, 0, 0, 0);                           \
     } while (0)
 

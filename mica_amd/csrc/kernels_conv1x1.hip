@@ -21,6 +21,13 @@
 // workgroups on purpose: two to three of them share a CU (43 KB of LDS each), out of phase, so that one's loads overlap another's
 // MFMAs and a third's epilogue stores - with one 8-wave workgroup per CU the kernel alternated between a read phase and a
 // write phase and reached 2.7 TB/s.
+// Tried in round 3 and dropped (tools: rocprofv3 kernel trace of bench.py): decoupling the activation stream from the weight
+// stream (vector-memory operations retire in order, so a wait for a weight fragment also waits for the younger-issued... older
+// activation loads) by requesting a whole pair's weight fragments one pair ahead and running the activation loads four pairs
+// ahead through a register ring, Cout = 256 as eight waves x two column tiles: 12-40 % SLOWER (<1> 747 -> 842 us, <2> 994 ->
+// 1158, <4> 2792 -> 3927): the register cost halves the workgroups per CU, and it is the number of independent workgroups on a
+// CU - one's VALU-heavy commit / epilogue beside another's MFMAs and a third's HBM waits - that keeps the three pipes busy, not
+// the bytes in flight.
 // LDS: two 16-KB stages of [chunk-in-pair 2][plane 4 = hi/lo x channel half][128 rows] 16-byte slots (a ds_read_b128 lane
 // group covers 16 consecutive slots), refilled one pair ahead: global loads for pair p+1 are issued before the MFMAs of
 // pair p and committed to LDS after them, one barrier per pair.
@@ -41,17 +48,7 @@ constexpr int C1_TAB = 2 * 512 * 2 * 4;                 // (mean, rstd) of up to
 constexpr int C1_LDS = (C1_TBYTES > 2 * C1_STAGE ? C1_TBYTES : 2 * C1_STAGE) + C1_TAB;
 
 __device__ __forceinline__ void c1_split8(const float (&y)[8], half8& hi, half8& lo, int& bad, float ascale) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float xs = y[j] * ascale;
-        if (!(fabsf(xs) <= F16_LIMIT)) {          // flag, and saturate so that an overflow cannot turn into Inf/NaN downstream
-            bad |= (fabsf(y[j]) <= 3.0e38f) ? RANGE_OVERFLOW : RANGE_NONFINITE;
-            xs = fminf(fmaxf(xs, -F16_LIMIT), F16_LIMIT);
-        }
-        const _Float16 h = (_Float16)xs;
-        hi[j] = h;
-        lo[j] = (_Float16)(xs - (float)h);
-    }
+    mica_split8(y, hi, lo, bad, ascale);
 }
 
 template <int NCT, bool WINO>
@@ -282,6 +279,7 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
     }
     if (bad2) atomicOr(enc.err, bad2);
 }
+
 
 bool conv1x1_can_emit_wino(Dims d) { return d.W >= 2 && d.W <= 64 && C1_ROWS % d.W == 0 && (d.W & 1) == 0; }
 

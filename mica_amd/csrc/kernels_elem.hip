@@ -187,17 +187,7 @@ void launch_finalize_sum(const float* ws, int B, int nblocks, int C, float inv, 
 // copy, optional global-average-pool of y (SE / calibration gates, model.py:216,244).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void split8(const float (&y)[8], half8& hi, half8& lo, int& bad, float ascale) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float xs = y[j] * ascale;
-        if (!(fabsf(xs) <= F16_LIMIT)) {          // flag, and saturate so that an overflow cannot turn into Inf/NaN downstream
-            bad |= (fabsf(y[j]) <= 3.0e38f) ? RANGE_OVERFLOW : RANGE_NONFINITE;
-            xs = fminf(fmaxf(xs, -F16_LIMIT), F16_LIMIT);
-        }
-        _Float16 h = (_Float16)xs;
-        hi[j] = h;
-        lo[j] = (_Float16)(xs - (float)h);
-    }
+    mica_split8(y, hi, lo, bad, ascale);
 }
 
 __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, int V, int C,
