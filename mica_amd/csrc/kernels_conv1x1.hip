@@ -22,12 +22,14 @@
 // MFMAs and a third's epilogue stores - with one 8-wave workgroup per CU the kernel alternated between a read phase and a
 // write phase and reached 2.7 TB/s.
 // Tried in round 3 and dropped (tools: rocprofv3 kernel trace of bench.py): decoupling the activation stream from the weight
-// stream (vector-memory operations retire in order, so a wait for a weight fragment also waits for the younger-issued... older
-// activation loads) by requesting a whole pair's weight fragments one pair ahead and running the activation loads four pairs
+// stream (vector-memory operations retire in order, so a wait for a weight fragment also waits for every activation load issued
+// before it) by requesting a whole pair's weight fragments one pair ahead and running the activation loads four pairs
 // ahead through a register ring, Cout = 256 as eight waves x two column tiles: 12-40 % SLOWER (<1> 747 -> 842 us, <2> 994 ->
 // 1158, <4> 2792 -> 3927): the register cost halves the workgroups per CU, and it is the number of independent workgroups on a
 // CU - one's VALU-heavy commit / epilogue beside another's MFMAs and a third's HBM waits - that keeps the three pipes busy, not
-// the bytes in flight.
+// the bytes in flight.  Also tried: padding the stage planes and XOR-swizzling the epilogue tile against the 20 % LDS bank-conflict
+// share the counters show (under a 32-bank and under a 64-bank model of the LDS): the counter went to 40 % and the kernels 2-4 %
+// slower both times; the kernel is not LDS-bound (LDS busy 21-32 % of the cycles), so the layout stays.
 // LDS: two 16-KB stages of [chunk-in-pair 2][plane 4 = hi/lo x channel half][128 rows] 16-byte slots (a ds_read_b128 lane
 // group covers 16 consecutive slots), refilled one pair ahead: global loads for pair p+1 are issued before the MFMAs of
 // pair p and committed to LDS after them, one barrier per pair.
