@@ -271,10 +271,13 @@ def main():
         dms, dl, dbytes = eng.profile(1)
         wms, wl, wflops = eng.profile(2)
         eng.set_profiling(False)
-        traffic = {}
-        tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")     # re-collected whenever the conv kernels change
-        if os.path.exists(tp) and B == 8 and not args.no_af:            # per launch at batch 8; independent of the map size
+        traffic, tp = {}, None
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))   # re-collected whenever the conv kernels change
+        if cands and B == 8 and not args.no_af:                         # per launch at batch 8; independent of the map size
+            tp = cands[-1]
             traffic = json.load(open(tp)).get("kernels", {})
+        tpn = os.path.basename(tp) if tp else "none"
         ach_all = flops / (ms * 1e-3) / 1e12
         wach = wflops / (wms * 1e-3) / 1e12 if wms > 0 else 0.0
         roof = {"bound": "mfma", "kernel": "conv_wino16_kernel: every dense 3x3x3 conv via Winograd F(2,3)-x, split-f16 x3 MFMA (v_mfma_f32_16x16x32_f16)",
@@ -289,11 +292,11 @@ def main():
                 "all_dense_convs": {"achieved": ach_all, "frac": ach_all / PEAK_SPLIT_TF, "launches_per_batch": launches,
                                     "note": "3x3x3 and 1x1x1 launches together (the 1x1 kernel is HBM-bound and also does the operand passes)"},
                 "note": "achieved = algorithmic direct-conv FLOPs (2*27*Cin*Cout*V, unpadded) of the conv_wino16_kernel launches of one batch / their "
-                        "HIP-event time (avg_launch_ms = the mean over its 22 launches: compare profiles/r02_final_bench512_b8_kernel_stats.txt, "
+                        "HIP-event time (avg_launch_ms = the mean over its 22 launches: compare the kernel-trace summary under profiles/ for this round, "
                         "three template variants); peak = f16 dense MFMA 2500 TF / 3 MFMAs per f32-grade product (833 TF); Winograd executes "
                         "1.5x fewer MFMAs than the algorithmic count, so `frac` is an algorithmic rate and `executed_mfma` the hardware fraction; "
                         "traffic = PMC HBM bytes per conv_wino16 launch at batch 8 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 "
-                        "corrections, profiles/r02_pmc_traffic.json); null for other batch sizes"}
+                        "corrections, profiles/" + tpn + "); null for other batch sizes"}
         dach = dbytes / (dms * 1e-3) / 1e9
         hbm = {"bound": "hbm", "kernel": "depthwise_kernel (Conv3d groups=C, 3x3x3, IN+ReLU+SE gate fused on load, IN stats fused)",
                "achieved": dach, "peak": 8000.0, "unit": "GB/s", "frac": dach / 8000.0,

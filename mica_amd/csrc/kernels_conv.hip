@@ -98,6 +98,12 @@ typedef float floatx4v __attribute__((ext_vector_type(4)));
 #define MICA_EXP_SLABOFF(x) (x)
 #define MICA_EXP_SLABBASE(b) (b)
 #endif
+// -DMICA_EXP_ROWFRAGS=n (n < 8): only the first n of a step's eight row fragments issue their MFMAs while every operand is still
+// moved - the operand bytes per MFMA of a 2-D Winograd variant (whose tiles hold 2 row fragments per weight fragment) at today's
+// instruction stream: measures how fast the weight / slab streams can run when the matrix pipe does not limit them.
+#ifndef MICA_EXP_ROWFRAGS
+#define MICA_EXP_ROWFRAGS 8
+#endif
 #ifdef MICA_EXP_W_FIXED
 #define MICA_EXP_WBASE(b) (wwave)
 #else
@@ -388,7 +394,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                     else if (ls + 1 < NS) ar[(fi + AD) % (AD + 1)] = W16_AFRAG(ab_nxt, f + AD - 8);
 #pragma unroll
                     for (int c = 0; c < NCT; ++c)
-                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(ar[fi % (AD + 1)]), "v"(bc[c]));
+                        if (f < MICA_EXP_ROWFRAGS)
+                            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(ar[fi % (AD + 1)]), "v"(bc[c]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 ab_cur = ab_nxt;

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out/abl
 for sh in "512 256" "256 512" "128 64" "64 64"; do
   set -- $sh
-  for v in normal SLAB_FIXED W_FIXED NOEPI; do
+  for v in normal SLAB_FIXED W_FIXED NOEPI ROWFRAGS=4 ROWFRAGS=2; do
     if [ $v = normal ]; then L=$PWD/mica_amd/lib/libmica_hip.so; else L=$PWD/tools/exp/libmica_$v.so; fi
     export MICA_HIP_LIB=$L
     timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abl/${v}_$1_$2 -o r -- python3 tools/conv_bench.py $1 $2 3 64 6 > gpurun_out/abl/${v}_$1_$2.log 2>&1
