@@ -40,7 +40,7 @@ class CryoEMPredictor:
         self.batch_size = batch_size
         self.reference_batching = bool(reference_batching)
         self.batch_threshold = 200          # utils/predict.py:72 (an instance attribute there too)
-        self.loader_threads = max(2, min(12, (os.cpu_count() or 8) - 2))      # tile-file readers beside the GPU
+        self.loader_threads = 2             # tile-file readers beside the GPU (more of them contend for the GIL: measured slower)
         self.use_optimized_batching = False
         self.optimal_batch_size = 1
         self.engine = None
@@ -139,18 +139,50 @@ class CryoEMPredictor:
                 pos += len(run)
             from concurrent.futures import ThreadPoolExecutor
             ahead = 3
-            with ThreadPoolExecutor(max_workers=self.loader_threads) as pool:
-                pending = [[pool.submit(dataset.__getitem__, t) for t in run] for run in runs[:ahead]]
+            copy_stream = torch.cuda.Stream(device=e.device)
+            main_stream = torch.cuda.current_stream(e.device)
+            pins = {}
+
+            def stage(r, futs):
+                """host side of run r, on a helper thread: wait for its tile files, assemble the batch in pinned memory (two
+                alternating buffers) and start the upload on the copy stream; -> (map tiles, AF3 tiles or None, event)"""
+                torch.cuda.set_device(e.device)
+                items = [f.result() for f in futs]
+                n, k = len(items), r & 1
+                if k not in pins:
+                    pins[k] = (torch.empty((B, 1, S, S, S), dtype=torch.float32).pin_memory(),
+                               torch.empty((B, 24, S, S, S), dtype=torch.float32).pin_memory())
+                px, pa = pins[k]
+                any_af = False
+                for q, it in enumerate(items):
+                    px[q].copy_(torch.from_numpy(it[0]))
+                    pa[q].copy_(torch.from_numpy(it[1]))
+                    any_af = any_af or bool(np.any(it[1]))
+                with torch.cuda.stream(copy_stream):
+                    x = px[:n].to(e.device, non_blocking=True)
+                    af = pa[:n].to(e.device, non_blocking=True) if any_af else None
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                return x, af, ev
+
+            with ThreadPoolExecutor(max_workers=self.loader_threads) as pool, ThreadPoolExecutor(max_workers=1) as stager:
+                loads = [[pool.submit(dataset.__getitem__, t) for t in run] for run in runs[:ahead]]
+                staged = [stager.submit(stage, 0, loads.pop(0))] if runs else []
                 for r, run in enumerate(runs):
-                    items = [f.result() for f in pending.pop(0)]
                     if r + ahead < len(runs):
-                        pending.append([pool.submit(dataset.__getitem__, t) for t in runs[r + ahead]])
-                    x = torch.from_numpy(np.stack([it[0] for it in items])).to(e.device)
-                    afh = np.stack([it[1] for it in items])
-                    af = torch.from_numpy(afh).to(e.device) if np.any(afh) else None
+                        loads.append([pool.submit(dataset.__getitem__, t) for t in runs[r + ahead]])
+                    if r + 1 < len(runs):
+                        # the pinned buffers of parity (r + 1) & 1 were last read by the upload of run r - 1, which the forward of
+                        # run r - 1 already waited for
+                        staged.append(stager.submit(stage, r + 1, loads.pop(0)))
+                    x, af, ev = staged.pop(0).result()
+                    main_stream.wait_event(ev)
                     n = len(run)
                     e.forward_records(x.view(n, S, S, S), af, rec[:n], af_mode=AF_PER_TILE)
                     e.stitch_tiles(rec[:n], out, grid, pad, tindex(run[0]))
+                    x.record_stream(main_stream)
+                    if af is not None:
+                        af.record_stream(main_stream)
             vols = {"backbone_probability": out[0].cpu().numpy(), "carbon_alpha_probability": out[1].cpu().numpy(),
                     "amino_acid_prediction": out[2].cpu().numpy(), "amino_acid_probability": out[3:].cpu().numpy()}
             self.timing_stats['inference'] = time.time() - t0

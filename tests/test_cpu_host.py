@@ -201,3 +201,22 @@ def test_af3_pdb_reader_and_oracle_rasteriser(tmp_path):
     # ... and x beyond nz-1 is silently clipped to nz-1
     v2 = ao.rasterise_atoms(np.array([[30, 0, 0]], np.float32), ["CA"], ["GLY"], (0, 0, 0), (4, 5, 40))
     assert v2[0, 0, 0, 3] == 1
+
+
+def test_fast_npz_grid_reader_equals_numpy(tmp_path):
+    """dataset.read_npz_grid (one fromfile behind the ZIP + npy headers) against np.load, incl. the fallbacks."""
+    from mica_amd.dataset import read_npz_grid
+    rng = np.random.default_rng(3)
+    for dt, shape in ((np.float32, (64, 64, 64)), (np.float64, (5, 6, 7)), (np.int16, (3, 4, 5))):
+        g = (rng.random(shape) * 100).astype(dt)
+        p = str(tmp_path / f"t_{np.dtype(dt).name}.npz")
+        np.savez(p, grid=g, i=1, j=2, k=3, orig_shape=shape, voxel_size=np.rec.array((1.0, 1.0, 1.0), dtype=[('x', '<f4'), ('y', '<f4'), ('z', '<f4')]))
+        got = read_npz_grid(p)
+        assert got.dtype == g.dtype and np.array_equal(got, g) and np.array_equal(got, np.load(p)['grid'])
+    g = rng.random((8, 8, 8)).astype(np.float32)
+    np.savez_compressed(str(tmp_path / "c.npz"), grid=g)                 # compressed member: falls back to np.load
+    assert np.array_equal(read_npz_grid(str(tmp_path / "c.npz")), g)
+    np.savez(str(tmp_path / "o.npz"), i=1, grid=g)                       # grid is not the first member: falls back
+    assert np.array_equal(read_npz_grid(str(tmp_path / "o.npz")), g)
+    np.savez(str(tmp_path / "f.npz"), grid=np.asfortranarray(rng.random((4, 5, 6))))   # Fortran order: falls back
+    assert np.array_equal(read_npz_grid(str(tmp_path / "f.npz")), np.load(str(tmp_path / "f.npz"))['grid'])

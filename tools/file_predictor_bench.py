@@ -32,7 +32,7 @@ try:
     T = r1["grid_count"]
     ck = os.path.join(tmp, "ckpt.pth")
     torch.save({"model_state_dict": {k: torch.from_numpy(v.copy()) for k, v in w.items()}}, ck)
-    for threads in (1, None):
+    for threads in (1, 2, 4):
         pred = CryoEMPredictor(ck, os.path.join(tmp, "grids") + "/", os.path.join(tmp, "out"), save_output=False, device="cuda", quiet=True)
         if threads:
             pred.loader_threads = threads
