@@ -3,10 +3,11 @@
 
 TEST INFRASTRUCTURE - never imported by the product path.
 
-PARITY UNPINNED: utils/preprocessing.py imports Bio and mrcfile at module top and neither is installed here, so the
-reference function cannot be executed; it holds no fixture for this step either.  The arithmetic below is the reference's
-own five numpy calls (subtract, divide by 1.0, np.round, astype(int), np.clip) applied in the reference's order, and the
-channel tables are copied as data from :254-260.
+PINNED (round 3): oracle/gen_golden_r3.py runs the reference's own DataPreprocessor.create_AF3_encodings (utils/preprocessing.py,
+imported unmodified under I/O-only adapters for `mrcfile` and `Bio.PDB`) on five synthetic atom lists and asserts that
+rasterise_atoms() equals the 24 channels it writes bit for bit, including the two non-cubic cases where its scatter raises IndexError
+(tests/golden/af3_ref.json).  The arithmetic below is the reference's own five numpy calls (subtract, divide by 1.0, np.round,
+astype(int), np.clip) applied in the reference's order; the channel tables are copied as data from :254-260.
 """
 from __future__ import annotations
 

@@ -2,10 +2,13 @@
 
 TEST INFRASTRUCTURE - never imported by the product path.
 
-PARITY UNPINNED against the reference module: utils/modeler.py imports open3d, mrcfile, superpose3d and Bio at module
-top (none installed), so Solver cannot be instantiated here and the reference holds no fixture for these steps.  The
-functions below are the reference's own numpy statements, copied as arithmetic (same calls, same order, same dtypes), so
-numpy itself is the witness for their floating-point behaviour.
+PINNED (round 3): oracle/gen_golden_r3.py runs the reference's own Solver.clustering (utils/modeler.py:762-899, unmodified, on a
+duck-typed `self`) with scikit-learn's DBSCAN standing in for open3d's - DBSCAN is the caller's step and outside this repo's
+scope; any labelling serves - and asserts that the functions below reproduce its CA_cands, CA_cands_AAProb, CA_cands_AA,
+cand_self_dis, the four neighbour lists and neigh_mat bit for bit (tests/golden/cluster_ref.json).  The functions are the
+reference's own numpy statements, copied as arithmetic (same calls, same order, same dtypes).  numpy here is 2.2.6; the one place
+where the reference's pinned numpy 1.19.1 computes differently (value-based promotion of the density sums) is stated explicitly
+by neighbour_matrix(..., numpy_legacy=True).
 """
 from __future__ import annotations
 

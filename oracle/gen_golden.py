@@ -3,12 +3,10 @@
 Run:  python oracle/gen_golden.py            (needs /root/reference; ~5 min on 8 cores)
 
 What is imported from the reference, unmodified: models.model.MICA, dataset.dataset,
-utils.predict.CryoEMPredictor.  utils/create_grids.py and utils/preprocessing.py are NOT
-importable here (they import `mrcfile`/`Bio`, which are absent and stay absent); their
-arithmetic is restated in oracle/volume_oracle.py and checked against the numbers the
-survey recorded from them - "parity unpinned" beyond that.
-The normaliser golden comes from the same numpy/scipy calls the reference makes
-(utils/preprocessing.py:117-133), evaluated with numpy %s / scipy %s.
+utils.predict.CryoEMPredictor.  (utils/create_grids.py, utils/preprocessing.py and utils/modeler.py
+are run by oracle/gen_golden_r3.py, round 3, under I/O-only adapters for the packages this image
+lacks; tiler.json / normaliser.json written HERE are the older restatement-only fixtures and are
+kept as additional regression data.)
 
 Only arrays (inputs regenerated from seeds, outputs stored) are committed; no reference
 source travels.

@@ -14,7 +14,8 @@ registers adapters for them in `sys.modules` and then imports the reference modu
   class.  No arithmetic either: everything that computes (transpose, pad, window loop, zoom, median,
   percentile, clip, the coordinate transform and scatter) is the reference's code, executed unmodified.
 
-Outputs (tests/golden/):  tiler_ref.json, normaliser_ref.json, normaliser_ref_*.npy, af3_ref.json.
+Outputs (tests/golden/):  tiler_ref.json, normaliser_ref.json, normaliser_ref_*.npy, af3_ref.json, cluster_ref.json
+(Solver.clustering behind a scikit-learn DBSCAN standing in for open3d's - see install_adapters).
 Every case also asserts that oracle/volume_oracle.py and oracle/af3_oracle.py reproduce the reference
 bit for bit, which is what pins those restatements.  Only data travels; no reference source.
 """
@@ -155,6 +156,28 @@ def install_adapters():
     pdb.PDBParser, pdb.PDBIO = _Parser, _PDBIO
     bio.PDB = pdb
     sys.modules["Bio"], sys.modules["Bio.PDB"] = bio, pdb
+    # utils/modeler.py (Solver.clustering) additionally imports open3d (only for DBSCAN, :768-770), superpose3d and three more
+    # Bio.PDB modules it does not use on this path.  DBSCAN is outside the scope of this repo (the caller's step): scikit-learn's
+    # DBSCAN, which IS installed, labels the points instead.  Any labelling serves: what the golden pins is the reference's
+    # arithmetic AFTER it (cluster scores, sorted greedy NMS, refinement, distances, neighbour matrix), run on these labels.
+    o3d, geo, util = types.ModuleType("open3d"), types.ModuleType("open3d.geometry"), types.ModuleType("open3d.utility")
+
+    class PointCloud:
+        points = None
+
+        def cluster_dbscan(self, eps, min_points):
+            from sklearn.cluster import DBSCAN
+            return DBSCAN(eps=eps, min_samples=min_points).fit(np.asarray(self.points, dtype=np.float64)).labels_.tolist()
+
+    geo.PointCloud, util.Vector3dVector = PointCloud, (lambda a: np.asarray(a))
+    o3d.geometry, o3d.utility = geo, util
+    sys.modules["open3d"], sys.modules["open3d.geometry"], sys.modules["open3d.utility"] = o3d, geo, util
+    sys.modules["superpose3d"] = types.ModuleType("superpose3d")
+    for name, cls in (("PDBParser", "PDBParser"), ("Structure", "Structure"), ("Model", "Model")):
+        m2 = types.ModuleType("Bio.PDB." + name)
+        setattr(m2, cls, _Parser if cls == "PDBParser" else type(cls, (), {}))
+        sys.modules["Bio.PDB." + name] = m2
+        setattr(pdb, name, m2)
     if REF not in sys.path:
         sys.path.insert(0, REF)
 
@@ -406,17 +429,81 @@ def af3_goldens(tmp):
     json.dump(out, open(os.path.join(OUT, "af3_ref.json"), "w"))
 
 
+def cluster_volumes(shape, seed):
+    """CAProb / BBProb / AAProb / AAPred volumes made of integer-hash uniforms and exact arithmetic only (comparisons, products,
+    one correctly rounded division): identical on every host.  Dense boxes of candidates (one of them on the x = 0 face, one with
+    weak backbone density, one tiny) over a quiet background."""
+    u = synth_density((4, *shape), seed)
+    boxes = [((6, 8, 6), (18, 20, 22)), ((26, 4, 10), (38, 14, 24)), ((0, 24, 28), (7, 33, 40)), ((30, 24, 30), (36, 30, 36)), ((20, 30, 4), (22, 32, 6))]
+    mask = np.zeros(shape, np.float32)
+    strong = np.zeros(shape, np.float32)
+    for n, (lo, hi) in enumerate(boxes):
+        sl = tuple(slice(a, b) for a, b in zip(lo, hi))
+        mask[sl] = 1.0
+        strong[sl] = (1.0, 0.9, 0.8, 0.35, 1.0)[n]
+    ca = (u[0] * (np.float32(0.25) + np.float32(0.75) * mask)).astype(np.float32)
+    bb = (u[1] * (np.float32(0.1) + np.float32(0.9) * strong)).astype(np.float32)
+    aa = synth_density((20, *shape), seed + 1) + np.float32(0.05)
+    aa = (aa / aa.sum(axis=0, keepdims=True)).astype(np.float32)
+    aapred = np.argmax(aa, axis=0).astype(np.float32)
+    return ca, bb, aa, aapred
+
+
+def cluster_goldens(_tmp):
+    import logging
+    import utils.modeler as M
+    from oracle import cluster_oracle as co
+    out = {"cases": []}
+    for shape, seed, eps, minpts, thr, radius in (((40, 36, 44), 91, 3, 10, 0.3, 9), ((40, 36, 44), 92, 2, 6, 0.45, 5)):
+        ca, bb, aa, aapred = cluster_volumes(shape, seed)
+        me = types.SimpleNamespace(logger=logging.getLogger("mica_golden_cluster"), cluster_eps=eps, cluster_min_points=minpts,
+                                   modeling_config=types.SimpleNamespace(CA_score_thrh=thr), CAProb=ca, AAPred=aapred, nms_radius=radius,
+                                   neighbors2to6=[], neighbors0to6=[], neighbors0to7=[], neighbors2to7=[])
+        M.NNPred.BBProb, M.NNPred.AAProb = bb, aa
+        M.Solver.clustering(me)                             # the reference method, unmodified, on a duck-typed self
+        # the same labels for the restatement: re-run the stand-in DBSCAN exactly as the method did
+        pts = co.threshold_points(ca, thr)
+        pc = sys.modules["open3d"].geometry.PointCloud()
+        pc.points = pts
+        labels = np.array(pc.cluster_dbscan(eps=eps, min_points=minpts))
+        sums, avgs, val = co.cluster_scores(bb, pts, labels)
+        pred = co.sorted_pred_list(ca, pts, val)
+        cands = np.array(co.nms(pred.copy(), thr, radius))
+        newc, newa, kept = co.refine_candidates(ca, aa, cands)
+        dis, lists, mat = co.neighbour_matrix(newc, bb)
+        assert len(kept) < len(cands), "a candidate on the volume face must be skipped"
+        assert np.array_equal(newc, me.CA_cands) and np.array_equal(newa.T, me.CA_cands_AAProb)
+        rc = np.round(newc).astype(int)
+        assert np.array_equal(co.gather(aapred, rc), me.CA_cands_AA)
+        assert np.array_equal(dis, me.cand_self_dis) and np.array_equal(mat, me.neigh_mat)
+        for mine, ref in zip(lists, (me.neighbors2to6, me.neighbors0to6, me.neighbors0to7, me.neighbors2to7)):
+            assert len(mine) == len(ref) and all(np.array_equal(a, b) for a, b in zip(mine, ref))
+        rec = {"shape": list(shape), "seed": seed, "eps": eps, "min_points": minpts, "thr": thr, "nms_radius": radius,
+               "n_points": int(len(pts)), "labels": labels.tolist(), "n_clusters": int(labels.max() + 1),
+               "scores_sum": [float(v) for v in sums], "scores_avg": [float(v) for v in avgs], "n_valid": int(val.sum()),
+               "nms_cands": cands.tolist(), "kept": kept.tolist(), "CA_cands": me.CA_cands.tolist(),
+               "CA_cands_AAProb_sha256": sha(me.CA_cands_AAProb), "CA_cands_AA": [float(v) for v in me.CA_cands_AA],
+               "cand_self_dis_sha256": sha(me.cand_self_dis), "neigh_mat_sha256": sha(me.neigh_mat),
+               "neigh_mat_nonzero": int((me.neigh_mat != 0).sum()), "best_neigh": [[int(v) for v in b] for b in me.best_neigh],
+               "numpy": np.__version__}
+        out["cases"].append(rec)
+        print("cluster", shape, seed, {k: rec[k] for k in ("n_points", "n_clusters", "n_valid", "neigh_mat_nonzero")}, "cands", len(cands), "kept", len(kept), flush=True)
+    json.dump(out, open(os.path.join(OUT, "cluster_ref.json"), "w"))
+
+
 def main():
     install_adapters()
     tmp = tempfile.mkdtemp(prefix="mica_golden_r3_")
     try:
-        which = sys.argv[1:] or ["tiler", "normaliser", "af3"]
+        which = sys.argv[1:] or ["tiler", "normaliser", "af3", "cluster"]
         if "tiler" in which:
             tiler_goldens(tmp)
         if "normaliser" in which:
             normaliser_goldens(tmp)
         if "af3" in which:
             af3_goldens(tmp)
+        if "cluster" in which:
+            cluster_goldens(tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -1,6 +1,10 @@
 """CPU restatement (numpy) of the reference's tiler, stitcher and map normaliser.
 
 TEST INFRASTRUCTURE - never imported by the product path.
+
+PINNED: tiler (transpose_axes, tile_volume) and normaliser (normalise_map) against the reference's own GridCreator /
+DataPreprocessor / training tiler run unmodified by oracle/gen_golden_r3.py (tests/golden/tiler_ref.json, normaliser_ref.json);
+the stitcher through the reference CryoEMPredictor goldens (oracle/gen_golden.py); zoom_cubic against the installed scipy.
 """
 from __future__ import annotations
 

@@ -183,6 +183,37 @@ def test_af3_oracle_vs_reference_run_goldens(golden_dir):
         assert sha(got) == c["sha256"] and int(got.sum()) == c["ones"] and len(flat) == c["n_atoms"]
 
 
+def _best_neigh(neigh_mat):
+    """modeler.py:890-899 (host numpy in the caller)."""
+    out = []
+    for cand in range(neigh_mat.shape[0]):
+        second, first = neigh_mat[cand].argsort()[-2:]
+        out.append([int(v) for v in ([first] if neigh_mat[cand, first] != 0 else []) + ([second] if neigh_mat[cand, second] != 0 else [])])
+    return out
+
+
+def test_cluster_oracle_vs_reference_run_goldens(golden_dir):
+    """Solver.clustering (utils/modeler.py:762-899) run by the reference itself on duck-typed state, DBSCAN labels from the golden."""
+    from oracle import cluster_oracle as co
+    from oracle.gen_golden_r3 import cluster_volumes
+    ref = json.load(open(os.path.join(golden_dir, "cluster_ref.json")))
+    assert len(ref["cases"]) == 2
+    for c in ref["cases"]:
+        ca, bb, aa, aapred = cluster_volumes(tuple(c["shape"]), c["seed"])
+        pts = co.threshold_points(ca, c["thr"])
+        labels = np.array(c["labels"])
+        assert len(pts) == c["n_points"] == len(labels)
+        sums, avgs, val = co.cluster_scores(bb, pts, labels)
+        assert [float(v) for v in sums] == c["scores_sum"] and [float(v) for v in avgs] == c["scores_avg"] and int(val.sum()) == c["n_valid"]
+        cands = np.array(co.nms(co.sorted_pred_list(ca, pts, val).copy(), c["thr"], c["nms_radius"]))
+        assert cands.tolist() == c["nms_cands"]
+        newc, newa, kept = co.refine_candidates(ca, aa, cands)
+        assert kept.tolist() == c["kept"] and newc.tolist() == c["CA_cands"] and sha(newa.T) == c["CA_cands_AAProb_sha256"]
+        assert [float(v) for v in co.gather(aapred, np.round(newc).astype(int))] == c["CA_cands_AA"]
+        dis, lists, mat = co.neighbour_matrix(newc, bb)
+        assert sha(dis) == c["cand_self_dis_sha256"] and sha(mat) == c["neigh_mat_sha256"] and _best_neigh(mat) == c["best_neigh"]
+
+
 def test_weights_table_and_generator_are_stable(weights):
     from mica_amd.weights import param_shapes, synth_state_dict
     shapes = param_shapes()

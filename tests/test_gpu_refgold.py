@@ -194,6 +194,37 @@ def test_af3_rasteriser_vs_reference_run_goldens(tmp_path, eng, golden_dir):
             assert sha(enc) == c["sha256"]
 
 
+def test_clustering_front_end_vs_reference_run_goldens(eng, golden_dir):
+    """Row f4: the reference's own Solver.clustering (utils/modeler.py:762-899; DBSCAN labels taken from the golden, that step is
+    the caller's) against the device helpers of mica_amd/clustering.py: threshold -> cluster scores -> sorted greedy NMS ->
+    refinement -> distances, neighbour lists, neighbour matrix, best neighbours.  Bit-exact."""
+    from mica_amd import clustering as cl
+    from oracle.gen_golden_r3 import cluster_volumes      # seeded input volumes only
+    ref = json.load(open(os.path.join(golden_dir, "cluster_ref.json")))
+    for c in ref["cases"]:
+        shape = tuple(c["shape"])
+        ca, bb, aa, aapred = cluster_volumes(shape, c["seed"])
+        vols = {"carbon_alpha_probability": torch.from_numpy(ca).cuda(), "backbone_probability": torch.from_numpy(bb).cuda(),
+                "amino_acid_probability": torch.from_numpy(aa).cuda(), "amino_acid_prediction": torch.from_numpy(aapred).cuda()}
+        pts, cav, bbv = cl.candidate_points(eng, vols, c["thr"])
+        labels = np.array(c["labels"])
+        assert len(pts) == c["n_points"]
+        sums, avgs, val = cl.cluster_scores(eng, bbv, labels)
+        assert [float(v) for v in sums] == c["scores_sum"] and [float(v) for v in avgs] == c["scores_avg"] and int(val.sum()) == c["n_valid"]
+        cands = cl.nms(eng, cav, pts, val, shape, c["thr"], c["nms_radius"])
+        assert cands.tolist() == c["nms_cands"]
+        newc, newa, kept = cl.refine(eng, vols, cands)
+        assert kept.tolist() == c["kept"] and newc.tolist() == c["CA_cands"] and sha(np.ascontiguousarray(newa.T)) == c["CA_cands_AAProb_sha256"]
+        assert [float(v) for v in cl.gather_at(eng, vols["amino_acid_prediction"], np.round(newc).astype(int))] == c["CA_cands_AA"]
+        dis, lists, mat = cl.neighbours(eng, vols, newc)            # numpy-2 promotion rules: the golden was evaluated with numpy 2.2.6
+        assert sha(dis) == c["cand_self_dis_sha256"] and sha(mat) == c["neigh_mat_sha256"] and int((mat != 0).sum()) == c["neigh_mat_nonzero"]
+        best = []
+        for i in range(mat.shape[0]):
+            second, first = mat[i].argsort()[-2:]
+            best.append([int(v) for v in ([first] if mat[i, first] != 0 else []) + ([second] if mat[i, second] != 0 else [])])
+        assert best == c["best_neigh"]
+
+
 # ---- BASELINE configs[1]/[2]: "stride-32 tiles" = grid 32 + 2 x 16 halo, the whole path, one rank and two -------------------
 SHAPE32, SEED32 = (70, 50, 40), 93
 
