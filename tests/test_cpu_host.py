@@ -220,3 +220,19 @@ def test_fast_npz_grid_reader_equals_numpy(tmp_path):
     assert np.array_equal(read_npz_grid(str(tmp_path / "o.npz")), g)
     np.savez(str(tmp_path / "f.npz"), grid=np.asfortranarray(rng.random((4, 5, 6))))   # Fortran order: falls back
     assert np.array_equal(read_npz_grid(str(tmp_path / "f.npz")), np.load(str(tmp_path / "f.npz"))['grid'])
+
+
+def test_tile_table_random_shapes_vs_oracle():
+    """mica_tile_table (host, pure integer) against the pinned tiler restatement on random shapes and tilings, including axes shorter
+    than one grid step, exact multiples (the reference still emits the last window, create_grids.py:130) and 1-voxel axes."""
+    from mica_amd._cabi import tile_table
+    from oracle import volume_oracle as vo
+    rng = np.random.default_rng(11)
+    cases = [(1, 1, 1, 48), (48, 96, 144, 48), (32, 64, 33, 32), (47, 49, 95, 48)]
+    cases += [tuple(int(v) for v in rng.integers(1, 140, size=3)) + (int(rng.choice([16, 32, 48])),) for _ in range(25)]
+    for n0, n1, n2, grid in cases:
+        pad = (64 - grid) // 2
+        _, idx = vo.tile_volume(np.zeros((n0, n1, n2), np.float32), grid, pad)
+        got = tile_table(n0, n1, n2, grid)
+        assert np.array_equal(got, idx), (n0, n1, n2, grid)
+        assert len(idx) == -(-n0 // grid) * -(-n1 // grid) * -(-n2 // grid)
