@@ -1,0 +1,134 @@
+"""`--check` mode shared by the golden generators (TEST INFRASTRUCTURE, build container only).
+
+A generator run with `--check` writes into a scratch directory instead of tests/golden/ and the files it
+produced are compared with the committed ones:
+
+* exact=True  (gen_golden_r3.py: integer / byte / bit-exact float work) - JSON documents must be equal as parsed
+  values, arrays must be equal bit for bit (dtype, shape, bytes);
+* exact=False (gen_golden.py, gen_golden_r2.py, gen_golden_r4.py: float32 network outputs of the reference
+  module, whose last bits depend on ATen's thread partition and CPU kernels) - arrays must agree within
+  `tol` in the tests' scaled metric max|a-b| / max(|b|, rms(b)); integer arrays and JSON leaves that are not
+  floats must be equal; float JSON leaves (recorded timings, measured distances) are not compared.
+
+Exit status of the generator = 0 only if every produced file has a committed twin and matches it.
+"""
+from __future__ import annotations
+
+import json
+import os
+import shutil
+import tempfile
+
+import numpy as np
+
+
+def _scaled(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    s = np.maximum(np.abs(b), np.sqrt(np.mean(b * b)))
+    s = np.where(s == 0, 1.0, s)
+    return float(np.max(np.abs(a - b) / s))
+
+
+def _cmp_array(name, a, b, exact, tol, log):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype != b.dtype or a.shape != b.shape:
+        log.append(f"{name}: dtype/shape {a.dtype}{a.shape} != {b.dtype}{b.shape}")
+        return
+    if a.dtype.kind in "fc" and not exact:
+        d = _scaled(a, b)
+        if not d <= tol:
+            log.append(f"{name}: scaled difference {d:.3e} > {tol:.1e}")
+    elif a.dtype.kind == "O" or a.tobytes() != b.tobytes():
+        if a.dtype.kind == "O" or not np.array_equal(a, b, equal_nan=a.dtype.kind in "fc"):
+            log.append(f"{name}: arrays differ")
+
+
+def _cmp_json(name, a, b, exact, log):
+    if isinstance(a, dict) and isinstance(b, dict):
+        if not exact:                                    # a partial run regenerates a subset of a shared manifest
+            keys = [k for k in a if k in b]
+        else:
+            keys = sorted(set(a) | set(b))
+        for k in keys:
+            if k not in a or k not in b:
+                log.append(f"{name}.{k}: present on one side only")
+            else:
+                _cmp_json(f"{name}.{k}", a[k], b[k], exact, log)
+    elif isinstance(a, list) and isinstance(b, list):
+        if len(a) != len(b):
+            log.append(f"{name}: list length {len(a)} != {len(b)}")
+        else:
+            for i, (x, y) in enumerate(zip(a, b)):
+                _cmp_json(f"{name}[{i}]", x, y, exact, log)
+    elif isinstance(a, float) or isinstance(b, float):
+        if exact and not (a == b or (a != a and b != b)):
+            log.append(f"{name}: {a!r} != {b!r}")
+    elif a != b:
+        log.append(f"{name}: {a!r} != {b!r}")
+
+
+def compare_dirs(produced, golden, exact=True, tol=2e-4):
+    """Compare every file under `produced` with its twin in `golden`; returns the list of differences."""
+    log = []
+    names = sorted(os.listdir(produced))
+    for f in names:
+        p, g = os.path.join(produced, f), os.path.join(golden, f)
+        if not os.path.exists(g):
+            log.append(f"{f}: not committed under tests/golden/")
+            continue
+        if f.endswith(".json"):
+            _cmp_json(f, json.load(open(p)), json.load(open(g)), exact, log)
+        elif f.endswith(".npy"):
+            _cmp_array(f, np.load(p), np.load(g), exact, tol, log)
+        elif f.endswith(".npz"):
+            zp, zg = np.load(p), np.load(g)
+            if sorted(zp.files) != sorted(zg.files):
+                log.append(f"{f}: keys {sorted(zp.files)} != {sorted(zg.files)}")
+                continue
+            for k in zp.files:
+                _cmp_array(f"{f}[{k}]", zp[k], zg[k], exact, tol, log)
+        elif open(p, "rb").read() != open(g, "rb").read():
+            log.append(f"{f}: bytes differ")
+    return names, log
+
+
+class CheckRun:
+    """with CheckRun(module_globals, argv, exact) as c:  ... generator body writes to module_globals['OUT'] ...
+
+    Without `--check` in argv it is a no-op.  With it, OUT points at a scratch copy (seeded with the files in `seed`,
+    e.g. a manifest the generator updates in place, which are compared too only if the generator rewrites them) and
+    on exit the produced files are compared; a difference raises SystemExit(1)."""
+
+    def __init__(self, g, argv, exact, seed=(), tol=2e-4):
+        self.g, self.exact, self.seed, self.tol = g, exact, seed, tol
+        self.on = "--check" in argv
+        self.argv = [a for a in argv if a != "--check"]
+
+    def __enter__(self):
+        if self.on:
+            self.golden = self.g["OUT"]
+            self.tmp = tempfile.mkdtemp(prefix="mica_golden_check_")
+            for f in self.seed:
+                shutil.copy(os.path.join(self.golden, f), os.path.join(self.tmp, f))
+            self.g["OUT"] = self.tmp
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if not self.on:
+            return False
+        try:
+            if et is None:
+                names, log = compare_dirs(self.tmp, self.golden, self.exact, self.tol)
+                for line in log:
+                    print("CHECK FAILED:", line)
+                print(f"check: {len(names)} files regenerated, {len(log)} differences "
+                      f"({'bit-exact' if self.exact else f'scaled tolerance {self.tol:.0e}'})", flush=True)
+                if log or not names:
+                    raise SystemExit(1)
+        finally:
+            self.g["OUT"] = self.golden
+            shutil.rmtree(self.tmp, ignore_errors=True)
+        return False

@@ -1,6 +1,7 @@
 """Generate tests/golden/* by running the REFERENCE's own Python (build container only).
 
-Run:  python oracle/gen_golden.py            (needs /root/reference; ~5 min on 8 cores)
+Run:  python oracle/gen_golden.py [--check]  (needs /root/reference; ~5 min on 8 cores)
+      --check regenerates into a scratch directory and compares with tests/golden/ (oracle/_check.py)
 
 What is imported from the reference, unmodified: models.model.MICA, dataset.dataset,
 utils.predict.CryoEMPredictor.  (utils/create_grids.py, utils/preprocessing.py and utils/modeler.py
@@ -53,6 +54,12 @@ def ref_model():
 
 
 def main():
+    from oracle._check import CheckRun
+    with CheckRun(globals(), sys.argv[1:], exact=False):   # float32 network outputs: scaled tolerance, see oracle/_check.py
+        _generate()
+
+
+def _generate():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     manifest = {"numpy": np.__version__, "torch": torch.__version__, "weights_seed": SEED_W,

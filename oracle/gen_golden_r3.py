@@ -1,6 +1,8 @@
 """Round-3 goldens: the reference's OWN tiler, normaliser and AF3 rasteriser, run unmodified (build container only).
 
-Run:  python oracle/gen_golden_r3.py          (needs /root/reference; about a minute)
+Run:  python oracle/gen_golden_r3.py [--check] [tiler] [normaliser] [af3] [cluster]   (needs /root/reference; about a minute)
+      --check regenerates into a scratch directory and compares bit for bit with tests/golden/ (oracle/_check.py);
+      tests/test_cpu_oracle.py::test_golden_generator_r3_check runs it whenever /root/reference is present.
 
 TEST INFRASTRUCTURE.  utils/create_grids.py, utils/preprocessing.py and the training tilers import two
 packages this image lacks, `mrcfile` and `Bio`.  Both are I/O only on this path, so this script
@@ -177,7 +179,8 @@ def install_adapters():
         m2 = types.ModuleType("Bio.PDB." + name)
         setattr(m2, cls, _Parser if cls == "PDBParser" else type(cls, (), {}))
         sys.modules["Bio.PDB." + name] = m2
-        setattr(pdb, name, m2)
+        if name != "PDBParser":          # `from Bio import PDB; PDB.PDBParser(...)` (preprocessing.py:52) must stay the class
+            setattr(pdb, name, m2)
     if REF not in sys.path:
         sys.path.insert(0, REF)
 
@@ -491,19 +494,21 @@ def cluster_goldens(_tmp):
     json.dump(out, open(os.path.join(OUT, "cluster_ref.json"), "w"))
 
 
-def main():
+def main(argv=None):
+    from oracle._check import CheckRun
     install_adapters()
     tmp = tempfile.mkdtemp(prefix="mica_golden_r3_")
     try:
-        which = sys.argv[1:] or ["tiler", "normaliser", "af3", "cluster"]
-        if "tiler" in which:
-            tiler_goldens(tmp)
-        if "normaliser" in which:
-            normaliser_goldens(tmp)
-        if "af3" in which:
-            af3_goldens(tmp)
-        if "cluster" in which:
-            cluster_goldens(tmp)
+        with CheckRun(globals(), sys.argv[1:] if argv is None else argv, exact=True) as chk:
+            which = chk.argv or ["tiler", "normaliser", "af3", "cluster"]
+            if "tiler" in which:
+                tiler_goldens(tmp)
+            if "normaliser" in which:
+                normaliser_goldens(tmp)
+            if "af3" in which:
+                af3_goldens(tmp)
+            if "cluster" in which:
+                cluster_goldens(tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

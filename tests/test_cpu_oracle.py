@@ -331,3 +331,40 @@ def test_zoom_restatement_is_bit_exact_vs_scipy(shape, factors):
     assert got.dtype == np.float32 and got.shape == ref.shape and np.array_equal(got, ref)
     if shape == (4, 1, 8):
         assert got.shape[0] == 188 and np.all(got[-1] == 0.0)      # scipy quirk reproduced
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
+def test_golden_generator_r3_check():
+    """The committed reference-run fixtures can be regenerated from the tree: `gen_golden_r3.py --check` runs the
+    reference's own tiler / normaliser / AF3 rasteriser / Solver.clustering again and compares bit for bit (≈ 15 s).
+    Guards the generator itself (round 3 shipped one whose normaliser and af3 legs crashed)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden_r3.py"), "--check"],
+                       capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0, tail
+    assert "0 differences (bit-exact)" in r.stdout, tail
+
+
+def test_check_mode_detects_a_changed_fixture(tmp_path, golden_dir):
+    """oracle/_check.py: equal files pass, a flipped bit / a changed JSON leaf / a missing twin are reported."""
+    import shutil
+    from oracle._check import compare_dirs
+    prod = tmp_path / "p"
+    prod.mkdir()
+    for f in ("tiler_ref.json", "normaliser_ref_f32_40.npy"):
+        shutil.copy(os.path.join(golden_dir, f), prod / f)
+    names, log = compare_dirs(str(prod), golden_dir, exact=True)
+    assert len(names) == 2 and log == []
+    a = np.load(prod / "normaliser_ref_f32_40.npy")
+    a.reshape(-1)[5] = np.nextafter(a.reshape(-1)[5], 2.0)
+    np.save(prod / "normaliser_ref_f32_40.npy", a)
+    j = json.load(open(prod / "tiler_ref.json"))
+    k = next(iter(j))
+    j[k] = {"changed": 1}
+    json.dump(j, open(prod / "tiler_ref.json", "w"))
+    (prod / "extra.json").write_text("{}")
+    _, log = compare_dirs(str(prod), golden_dir, exact=True)
+    assert len(log) >= 3, log
+    _, log2 = compare_dirs(str(prod), golden_dir, exact=False, tol=1e-4)      # one ulp is inside the float tolerance
+    assert not any("normaliser_ref_f32_40" in line for line in log2)
