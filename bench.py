@@ -6,6 +6,8 @@ One JSON line on rank 0.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
   python bench.py --gpus N ...          (no launcher: this process touches no GPU and starts the N ranks itself)
   python bench.py --gpus 2 --backend gloo --single-device      (rehearse the N>1 path on one GPU)
+  python bench.py --gpus 1 --backend nccl --force-exchange     (one rank, RCCL all-gather per step: the production branch on one GPU)
+  python bench.py --gpus N --strong                            (strong scaling: ONE complete map sharded over N ranks, stitch + D2H timed)
 
 A step = one batch of `--batch` tiles per GPU through the whole path.  The map is the synthetic 512^3 map at
 every N (it fits one GPU: 0.54 GB map + 12.9 GB encodings + 12.3 GB output volumes + ~40 GB workspace);
@@ -122,6 +124,12 @@ def main():
     ap.add_argument("--no-whole-map", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="with --gpus 1: a process group of ONE rank whose record exchange still runs the collective "
+                         "(--backend nccl executes the RCCL all_gather_into_tensor(async_op=True) branch on one GPU)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong-scaling mode: ONE complete map, every window, sharded over the ranks (predict_volume_sharded), rank-0 "
+                         "stitch and the final D2H of the four volumes inside the clock; --steps/--warmup are ignored")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -144,8 +152,17 @@ def main():
     if args.single_device:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    grouped = world > 1 or args.force_exchange
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            sk.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -178,13 +195,14 @@ def main():
         return ((k * world + r) % nb) * B
 
     ex = None
-    if world > 1:
+    if grouped:
         # cropped records carry no halo: stitched with pad 0 on a grid-sized window
-        ex = RecordExchange(B, (23, g3, g3, g3), dev, lambda rec, first: eng.stitch_tiles(rec, out, g3, 0, first), stitch_rank=0)
+        ex = RecordExchange(B, (23, g3, g3, g3), dev, lambda rec, first: eng.stitch_tiles(rec, out, g3, 0, first), stitch_rank=0,
+                            force_collective=args.force_exchange)
 
     def step(k, pred=vp, grid=g3, pad=p):
         rec = pred.run_batch(vol, af, first_of(k, rank), B)
-        if world == 1:
+        if ex is None:
             eng.stitch_tiles(rec, out, grid, pad, first_of(k, 0))
         else:
             ex.post(k, rec[:, :, p:p + g3, p:p + g3, p:p + g3], [(first_of(k, r), B) for r in range(world)])
@@ -193,9 +211,46 @@ def main():
         if ex is not None:
             ex.flush()
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.strong:
+        # ---- strong scaling: one complete map, fixed total work, everything the caller waits for inside the clock ----
+        step(0)                                            # one untimed batch: kernels loaded, buffers touched
+        sync()
+        del out
+        out = None
+        host = torch.empty((23, n, n, n), dtype=torch.float32).pin_memory() if rank == 0 else None
+        sync()
+        t0 = time.perf_counter()
+        stats = {}
+        vols = vp.predict_volume_sharded(vol, af, force_collective=args.force_exchange, stats=stats) if grouped else vp.predict_volume(vol, af)
+        if rank == 0:
+            host.copy_(vols["backbone_probability"]._base, non_blocking=True)
+        sync()
+        dt = time.perf_counter() - t0
+        if grouped:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        if rank == 0:
+            chk = float(host[3:, ::16, ::16, ::16].sum(dim=0).sub(1).abs().max())
+            rounds = (T + B * world - 1) // (B * world)
+            print(json.dumps({
+                "metric": "64^3 sub-grids/sec", "value": T / dt, "unit": "sub-grids/s", "n_gpus": world, "steps": rounds, "warmup": 1,
+                "ms_per_step": dt / rounds * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32 (3x f16 MFMA split products, f32 accumulate)", "data": "synthetic",
+                "config": {"workload": f"ONE complete synthetic {n}^3 density map + 24-ch AF3 encodings, every one of its {T} windows (64 = grid "
+                                       f"{args.grid} + 2x{args.pad} halo) sharded over {world} rank(s), gather+forward+softmax, "
+                                       + (f"{'RCCL' if args.backend == 'nccl' else args.backend} all-gather of cropped records, " if grouped else "")
+                                       + "rank-0 stitch and the D2H of the four volumes (12.3 GB at 512^3) inside the clock",
+                           "backend": args.backend if grouped else None, "tiles": T, "seconds_per_map": dt, "collectives": stats.get("collectives"),
+                           "softmax_sum_check": chk, "af_path": not args.no_af}}), flush=True)
+        if grouped:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     for k in range(args.warmup):
         step(k)
@@ -205,7 +260,7 @@ def main():
         step(args.warmup + k)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -317,14 +372,15 @@ def main():
             "vs_baseline": None, "dtype": "f32 (3x f16 MFMA split products, f32 accumulate)", "data": "synthetic",
             "config": {"workload": f"synthetic {n}^3 density map + 24-ch AF3 encodings, window 64 = grid {args.grid} + 2x{args.pad} halo, "
                                    f"{T} tiles per map, {B} tiles per step per GPU, gather+forward+softmax+stitch"
-                                   + ("" if world == 1 else f", {'RCCL' if args.backend == 'nccl' else args.backend + ' (rehearsal, host-staged)'} "
-                                      "all-gather of cropped records to every rank, rank 0 stitches")
+                                   + ("" if not grouped else f", {'RCCL' if args.backend == 'nccl' else args.backend + ' (rehearsal, host-staged)'} "
+                                      "all-gather of cropped records to every rank, rank 0 stitches"
+                                      + (f" (collective forced in a group of one rank; {ex.collectives} all-gathers issued)" if world == 1 else ""))
                                    + (", every rank on cuda:0" if args.single_device else ""),
-                       "backend": None if world == 1 else args.backend,
+                       "backend": args.backend if grouped else None,
                        "tiles_per_step": B * world, "af_path": not args.no_af, "flops_per_tile": FLOPS_PER_TILE_AF,
                        "seconds_per_map": T / value},
             "alt_tiling": alt, "whole_map": whole, "roofline": roof, "hbm_conv3d": hbm, "cpu_baseline": cpu}), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()                          # rank 0 ran the extra profiled batch: leave together
         dist.destroy_process_group()
 

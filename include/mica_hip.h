@@ -56,6 +56,13 @@ int mica_load_weight(mica_ctx* ctx, const char* name, const float* h_data, const
  * kernels' layouts (split-f16 [cin/16][tap][hi|lo][k-half][Cout][8]); blocks until done.      */
 int mica_finalize_weights(mica_ctx* ctx);
 
+/* Which dense 3x3x3 convs run on the Winograd F(4,3)-along-x kernel (1.33x fewer MFMAs, ~4x the per-layer rounding error) instead
+ * of F(2,3): 0 = none, 1 = the four convs of encoder.2 (models/model.py:107,115,122,142 at C = 256: 68 % of the network's FLOPs;
+ * whole-network error indistinguishable from mode 0, profiles/r04_wino_network_numerics.txt) - the default, also settable through
+ * the environment (MICA_F43=0|1, read by mica_create).  The variant decides how weights are packed: before mica_finalize_weights. */
+int mica_set_conv_variant(mica_ctx* ctx, int mode);
+int mica_get_conv_variant(const mica_ctx* ctx);
+
 /* ---- inner boundary: MICA.forward (model.py:331-348) ------------------------------------ */
 /* d_map f32[B][1][S^3], d_af f32[B][24][S^3] or NULL (NCDHW, S = tile_size)
  * -> logits d_bb f32[B][4][S^3], d_ca f32[B][4][S^3], d_aa f32[B][21][S^3] (NCDHW).           */
@@ -185,11 +192,19 @@ int mica_neighbour_matrix_np(mica_ctx* ctx, const double* d_cands, int64_t n, co
  * d_x f32[B][Cin][D][H][W] NCDHW, h_w f32[Cout][Cin][k][k][k], h_b f32[Cout] -> d_y f32[B][Cout][D][H][W]. */
 int mica_op_conv3d(mica_ctx* ctx, const float* d_x, int batch, int cin, int d, int h, int w,
                    const float* h_w, const float* h_b, int cout, int k, float* d_y, void* stream);
+/* The same with the kernel named: variant 0 = Winograd F(2,3) along x (every layer's default), 1 = F(4,3) along x (k = 3 and
+ * cout a multiple of 128: the kernel encoder.2's convs run on).                                                          */
+int mica_op_conv3d_variant(mica_ctx* ctx, const float* d_x, int batch, int cin, int d, int h, int w,
+                           const float* h_w, const float* h_b, int cout, int k, int variant, float* d_y, void* stream);
 /* conv3x3x3(conv1x1x1(relu(InstanceNorm3d(x)))), NCDHW in and out: the fused form the forward graph uses for
  * dual_attn.fusion -> transition and FPN lateral -> smooth (model.py:96,141-147,182-205) - the 1x1x1 kernel applies the norm +
  * ReLU on load and writes the Winograd operand of the 3x3x3 conv when the tile width allows, else through the operand pass. */
 int mica_op_norm_conv1_conv3(mica_ctx* ctx, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w1,
                              const float* h_b1, int cmid, const float* h_w3, const float* h_b3, int cout, float* d_y, void* stream);
+/* ... with the 3x3x3 conv's variant named (as mica_op_conv3d_variant): the 1x1x1 kernel then emits the F(4,3) operand. */
+int mica_op_norm_conv1_conv3_variant(mica_ctx* ctx, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w1,
+                                     const float* h_b1, int cmid, const float* h_w3, const float* h_b3, int cout, int variant,
+                                     float* d_y, void* stream);
 /* InstanceNorm3d(affine=False, eps=1e-5) + ReLU on NCDHW (model.py:81-82,108-109). */
 int mica_op_instnorm_relu(mica_ctx* ctx, const float* d_x, int batch, int c, int d, int h, int w,
                           float* d_y, void* stream);
@@ -225,8 +240,9 @@ int mica_set_activation_scale(mica_ctx* ctx, float scale);
 int mica_set_profiling(mica_ctx* ctx, int enable);
 int mica_get_conv_profile(mica_ctx* ctx, double* h_ms_total, int64_t* h_launches, double* h_flops);
 /* kind 0 = dense conv launches (work = algorithmic FLOPs; = kinds 2 + 4), kind 1 = depthwise conv3d launches (work =
- * algorithmic HBM bytes, 8 B per voxel and channel), kind 2 = 3x3x3 convs only, kind 3 = operand passes (InstanceNorm
- * apply + ReLU + re-encode; work = algorithmic bytes), kind 4 = 1x1x1 convs only.                  */
+ * algorithmic HBM bytes, 8 B per voxel and channel), kind 2 = 3x3x3 convs on the F(2,3) kernel, kind 3 = operand passes
+ * (InstanceNorm apply + ReLU + re-encode; work = algorithmic bytes), kind 4 = 1x1x1 convs only, kind 5 = 3x3x3 convs on the
+ * F(4,3) kernel (kind 0 = kinds 2 + 4 + 5).                                                       */
 int mica_get_profile(mica_ctx* ctx, int kind, double* h_ms_total, int64_t* h_launches, double* h_work);
 
 #ifdef __cplusplus

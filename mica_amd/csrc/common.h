@@ -93,9 +93,11 @@ struct Conv1Srcs { Conv1Src s[2]; int n; };
 // 1x1x1 conv, cout in {64, 128, 256}: out = acc * out_scale + bias written either as raw f32 [B][V][cout] (out_raw) or straight
 // as the Winograd operand of the 3^3 conv that follows (wino; needs conv1x1_can_emit_wino(d): whole x rows per workgroup).
 // wpk as launch_pack_weights(ksize = 1) lays it out.
+// wino_kind: 1 = the F(2,3) operand, 2 = the F(4,3) operand (kernels_conv43.hip; enc_out.ascale = that operand's scale).
+// `enc` scales the split encoding of RAW sources staged for the MFMAs and must match out_scale; `enc_out` scales the emitted operand.
 void launch_conv1x1(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out_raw,
-                    SplitView wino, int B, Dims d, int cout, SplitEnc enc, hipStream_t st);
-bool conv1x1_can_emit_wino(Dims d);
+                    SplitView wino, int B, Dims d, int cout, SplitEnc enc, hipStream_t st, int wino_kind = 1, float enc_out_ascale = 0.f);
+bool conv1x1_can_emit_wino(Dims d, int wino_kind = 1);
 // Pack torch-layout conv weights into wpk.  seg_c/seg_cp: per-source real and padded channel counts.
 // cin_scale f32[B][Cin] (nullable) multiplies input channels (gate folding); cout_scale scalar.
 void launch_pack_weights(const float* w, int cout, int cin, int ksize, const int* h_seg_c, const int* h_seg_cp,
@@ -161,6 +163,18 @@ void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_se
                               const float* cin_scale, int B, float cout_scale, float wscale, _Float16* wpk,
                               hipStream_t st);
 int64_t packed_weight_halves_wino(int cout, int total_chunks);
+// ---- Winograd F(4,3) along x (kernels_conv43.hip; the 3^3 convs of encoder.2): operand layout [B][chunks][6 p][4 q][Vq][8],
+// Vq = D*H*ceil(W/4); `enc.ascale` of its producers is the OPERAND's scale (callers pass ascale / WINO43_ASCALE_DIV)
+constexpr float WINO43_ASCALE_DIV = 4.0f;
+bool conv_wino43_eligible(int cout);
+void launch_prep_wino43(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, int relu, SplitView wino,
+                        SplitEnc enc, hipStream_t st);
+void launch_prep_ncdhw_wino43(const float* x, int B, Dims d, int C, SplitView wino, SplitEnc enc, hipStream_t st);
+int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out,
+                       int B, Dims d, int cout, float* stats_ws, hipStream_t st);
+void launch_pack_weights_wino43(const float* w, int cout, int cin, const int* h_seg_c, const int* h_seg_cp, int nseg,
+                                const float* cin_scale, int B, float cout_scale, float wscale, _Float16* wpk, hipStream_t st);
+int64_t packed_weight_halves_wino43(int cout, int total_chunks);
 void launch_postprocess(const float* bb, const float* ca, const float* aa, int B, int V, float* bbp, float* cap,
                         float* aap, float* aapred, int64_t s1, int64_t s20, hipStream_t st);
 

@@ -31,7 +31,8 @@ struct ConvLayer {
     float cout_scale = 1.f;           // folded output scale (FPN softmax weight, model.py:201-205)
     float wscale = 1.f;               // power of two bringing max|w| to ~4096 (f16 hi/lo stay normal)
     bool per_tile = false;            // weights re-packed per tile with a gate folded in (cin_scale)
-    bool wino = false;                // 3^3 conv: Winograd F(2,3)-along-x kernel and operand layout
+    bool wino = false;                // 3^3 conv: Winograd-along-x kernel and operand layout
+    bool f43 = false;                 // ... F(4,3) (kernels_conv43.hip: the 3^3 convs of encoder.2) instead of F(2,3)
     float* d_w = nullptr;             // torch layout f32
     float* d_b = nullptr;             // bias (already times cout_scale)
     _Float16* d_wpk = nullptr;        // packed (static) or per-tile buffer [maxB][...]
@@ -61,7 +62,7 @@ struct Head {
 
 }  // namespace
 
-constexpr int PROF_KINDS = 5;
+constexpr int PROF_KINDS = 6;
 
 struct mica_ctx {
     int device = 0, maxB = 1, S = 64;
@@ -93,6 +94,7 @@ struct mica_ctx {
     float *v_mean, *v_rstd, *v_mean3, *v_rstd3, *v_pool, *v_gse, *v_gate, *v_abs;
     int* d_err = nullptr;
     float ascale = ASCALE_DEFAULT;   // activation scale of the split encoding (common.h) every forward call starts from
+    int f43_mode = 1;                // 0: every 3^3 conv on the F(2,3) kernel; 1: encoder.2's four convs on the F(4,3) kernel (default)
     float last_scale = ASCALE_DEFAULT;   // the lowest scale a tile of the last forward call needed (forward_checked)
     std::vector<char> use_af;        // per tile of the last forward_impl call: AF3 branch taken
     float* h_abs = nullptr;       // pinned
@@ -163,7 +165,7 @@ float pick_wscale(const std::vector<float>& w, float cs) {
 }
 
 int setup_conv(mica_ctx* c, ConvLayer& L, const std::string& name, int cout, int k, std::vector<int> seg_c, bool per_tile,
-               float cout_scale = 1.f) {
+               float cout_scale = 1.f, bool f43 = false) {
     L.name = name;
     L.cout = cout;
     L.k = k;
@@ -193,13 +195,18 @@ int setup_conv(mica_ctx* c, ConvLayer& L, const std::string& name, int cout, int
     r = upload(c, &L.d_b, bs);
     if (r) return r;
     L.wino = (k == 3);
-    L.pk_halves = L.wino ? packed_weight_halves_wino(cout, L.total_chunks) : packed_weight_halves(cout, k, L.total_chunks);
+    L.f43 = L.wino && f43 && conv_wino43_eligible(cout);
+    L.pk_halves = L.f43 ? packed_weight_halves_wino43(cout, L.total_chunks)
+                        : L.wino ? packed_weight_halves_wino(cout, L.total_chunks) : packed_weight_halves(cout, k, L.total_chunks);
     r = dalloc(c, &L.d_wpk, L.pk_halves * (per_tile ? c->maxB : 1));
     if (r) return r;
     if (per_tile) {
         r = dalloc(c, &L.d_cin_scale, (int64_t)c->maxB * L.cin);
         if (r) return r;
         launch_fill_float(L.d_cin_scale, (int64_t)c->maxB * L.cin, 1.0f, 0);
+    } else if (L.f43) {
+        launch_pack_weights_wino43(L.d_w, cout, L.cin, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(), nullptr, 1, cout_scale,
+                                   L.wscale, L.d_wpk, 0);
     } else if (L.wino) {
         launch_pack_weights_wino(L.d_w, cout, L.cin, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(), nullptr, 1, cout_scale,
                                  L.wscale, L.d_wpk, 0);
@@ -257,9 +264,11 @@ void prof_end(mica_ctx* c, int kind, double work, hipStream_t st) {
 // produced too (fused into the kernel's epilogue, merged by stats_finalize).
 void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, hipStream_t st, float* mean = nullptr,
               float* rstd = nullptr) {
-    prof_begin(c, 2, st);
-    const int P = launch_conv_wino(src.s, L.d_wpk, 0, L.d_b, 1.0f / (L.wscale * c->ascale), out, B, c->d, L.cout, mean ? c->ws : nullptr, st);
-    prof_end(c, 2, L.flops_per_voxel * (double)c->V * B, st);
+    prof_begin(c, L.f43 ? 5 : 2, st);
+    const int P = L.f43 ? launch_conv_wino43(src.s, L.d_wpk, 0, L.d_b, 1.0f / (L.wscale * (c->ascale / WINO43_ASCALE_DIV)), out, B, c->d, L.cout,
+                                             mean ? c->ws : nullptr, st)
+                        : launch_conv_wino(src.s, L.d_wpk, 0, L.d_b, 1.0f / (L.wscale * c->ascale), out, B, c->d, L.cout, mean ? c->ws : nullptr, st);
+    prof_end(c, L.f43 ? 5 : 2, L.flops_per_voxel * (double)c->V * B, st);
     if (mean) launch_stats_finalize(c->ws, B, P, L.cout, 1e-5f, mean, rstd, st);
 }
 
@@ -271,11 +280,12 @@ Conv1Src raw_src(const float* p, int channels, const float* mean, const float* r
 }
 
 void make_operand(mica_ctx* c, const float* raw, int B, int C, const float* mean, const float* rstd, int relu, SplitView t3, SplitView t1,
-                  float* gap, hipStream_t st);
+                  float* gap, hipStream_t st, bool f43 = false);
 
 // A 1x1x1 conv whose output is the Winograd operand `dst` of the 3^3 conv that follows.  The kernel writes the operand itself
 // when a workgroup owns whole x rows; otherwise it writes raw f32 to `tmp_raw` and the operand pass follows.
-void run_conv1x1(mica_ctx* c, ConvLayer& L, Conv1Src a, const Conv1Src* b2, SplitView dst, float* tmp_raw, int B, hipStream_t st) {
+void run_conv1x1(mica_ctx* c, ConvLayer& L, Conv1Src a, const Conv1Src* b2, SplitView dst, float* tmp_raw, int B, hipStream_t st,
+                 bool f43 = false) {
     if (L.per_tile)
         launch_pack_weights(L.d_w, L.cout, L.cin, 1, L.seg_c.data(), L.seg_cp.data(), (int)L.seg_c.size(), L.d_cin_scale, B, L.cout_scale,
                             L.wscale, L.d_wpk, st);
@@ -283,12 +293,13 @@ void run_conv1x1(mica_ctx* c, ConvLayer& L, Conv1Src a, const Conv1Src* b2, Spli
     src.n = b2 ? 2 : 1;
     src.s[0] = a;
     if (b2) src.s[1] = *b2;
-    const bool fused = conv1x1_can_emit_wino(c->d);
+    const bool fused = conv1x1_can_emit_wino(c->d, f43 ? 2 : 1);
     prof_begin(c, 4, st);
     launch_conv1x1(src, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * c->ascale), fused ? nullptr : tmp_raw,
-                   fused ? dst : SplitView{nullptr, 0, 0, 0}, B, c->d, L.cout, SplitEnc{c->d_err, c->ascale}, st);
+                   fused ? dst : SplitView{nullptr, 0, 0, 0}, B, c->d, L.cout, SplitEnc{c->d_err, c->ascale}, st, f43 ? 2 : 1,
+                   f43 ? c->ascale / WINO43_ASCALE_DIV : c->ascale);
     prof_end(c, 4, L.flops_per_voxel * (double)c->V * B, st);
-    if (!fused) make_operand(c, tmp_raw, B, L.cout, nullptr, nullptr, 0, dst, SplitView{nullptr, 0, 0, 0}, nullptr, st);
+    if (!fused) make_operand(c, tmp_raw, B, L.cout, nullptr, nullptr, 0, dst, SplitView{nullptr, 0, 0, 0}, nullptr, st, f43);
 }
 
 void gate(mica_ctx* c, const GateMLP& g, const float* pool, const float* premul, int B, const float* postmul, float* out,
@@ -299,12 +310,15 @@ void gate(mica_ctx* c, const GateMLP& g, const float* pool, const float* premul,
 // Re-encode a raw conv output as the operand(s) of its consumers: `t3` feeds 3^3 convs (wino layout when the
 // Winograd path is on, else plain split), `t1` feeds 1x1 convs (always plain split).  Either may be empty.
 void make_operand(mica_ctx* c, const float* raw, int B, int C, const float* mean, const float* rstd, int relu, SplitView t3,
-                  SplitView t1, float* gap, hipStream_t st) {
+                  SplitView t1, float* gap, hipStream_t st, bool f43) {
     prof_begin(c, 3, st);
-    // algorithmic bytes: the f32 tensor read once, each operand written once (wino layout = 8 B, plain split = 4 B per value)
-    const double bytes = (double)B * c->V * C * (4.0 + (t3.p ? 8.0 : 0.0) + (t1.p ? 4.0 : 0.0));
+    // algorithmic bytes: the f32 tensor read once, each operand written once (wino layout = 8 B, wino43 = 6 B, plain split = 4 B per value)
+    const double bytes = (double)B * c->V * C * (4.0 + (t3.p ? (f43 ? 6.0 : 8.0) : 0.0) + (t1.p ? 4.0 : 0.0));
     struct End { mica_ctx* c; double b; hipStream_t s; ~End() { prof_end(c, 3, b, s); } } end_{c, bytes, st};
-    if (t3.p) {
+    if (t3.p && f43) {
+        // F(4,3) operand of encoder.2's convs: no plain / pooled side outputs are ever wanted there
+        launch_prep_wino43(raw, B, c->d, C, mean, rstd, relu, t3, SplitEnc{c->d_err, c->ascale / WINO43_ASCALE_DIV}, st);
+    } else if (t3.p) {
         launch_prep_wino(raw, B, c->d, C, mean, rstd, relu, nullptr, t3, t1, gap, c->ws, SplitEnc{c->d_err, c->ascale}, st);
     } else {
         launch_prep(raw, B, c->V, C, mean, rstd, relu, nullptr, t1, nullptr, gap, c->ws, SplitEnc{c->d_err, c->ascale}, st);
@@ -336,11 +350,14 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
     for (int e = 0; e < 3; ++e) {
         Enc& E = c->enc[e];
         const int C = E.C, cc = C / 16, ch = C / 32;   // chunks of C and of C/2
+        // encoder.2's four 3^3 convs run on the F(4,3) kernel: every operand they read (x = c_1, x1, x2, the fusion's output) is
+        // written in that kernel's layout by its producer; no tensor is needed in both layouts
+        const bool f43 = E.conv1.f43, f43_next = e < 2 && c->enc[e + 1].conv1.f43;
         // ResidualDenseBlock (model.py:130-134)
         run_conv(c, E.conv1, SrcList().add(X, cc, 0, cc), c->R_a, B, st, c->v_mean, c->v_rstd);
-        make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_1, ch, 0, ch), none, nullptr, st);
+        make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_1, ch, 0, ch), none, nullptr, st, f43);
         run_conv(c, E.conv2, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch), c->R_a, B, st, c->v_mean, c->v_rstd);
-        make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_2, ch, 0, ch), none, nullptr, st);
+        make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_2, ch, 0, ch), none, nullptr, st, f43);
         run_conv(c, E.conv3, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch).add(c->S_2, ch, 0, ch), c->R_b, B, st, c->v_mean3,
                  c->v_rstd3);
         // x3 = relu(IN(conv3)) is never materialised: the depthwise conv and the 1x1 fusion normalise the raw tensor on load,
@@ -362,11 +379,11 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         {
             // fusion (model.py:96, 101) reads the two branches raw: local = relu(IN(depthwise)), global = relu(IN(conv3)) * gates
             const Conv1Src glob = raw_src(c->R_b, C, c->v_mean3, c->v_rstd3, 1);
-            run_conv1x1(c, E.fusion, raw_src(c->R_c, C, c->v_mean, c->v_rstd, 1), &glob, view(c->S_f, cc, 0, cc), c->R_a, B, st);
+            run_conv1x1(c, E.fusion, raw_src(c->R_c, C, c->v_mean, c->v_rstd, 1), &glob, view(c->S_f, cc, 0, cc), c->R_a, B, st, f43);
         }
         // transition (model.py:141-147); c_e feeds the next encoder's 3^3 convs and the FPN's 1x1 lateral
         run_conv(c, E.transition, SrcList().add(c->S_f, cc, 0, cc), c->R_a, B, st, c->v_mean, c->v_rstd);
-        if (e < 2) make_operand(c, c->R_a, B, 2 * C, c->v_mean, c->v_rstd, 1, view(c->S_c[e], 2 * cc, 0, 2 * cc), none, nullptr, st);
+        if (e < 2) make_operand(c, c->R_a, B, 2 * C, c->v_mean, c->v_rstd, 1, view(c->S_c[e], 2 * cc, 0, 2 * cc), none, nullptr, st, f43_next);
         // FPN level e right away (model.py:182-205; the interpolations are identities): the lateral 1x1 reads c_e raw with the
         // transition's InstanceNorm + ReLU applied on load, and writes the smoothing conv's operand
         run_conv1x1(c, c->lateral[e], raw_src(c->R_a, 2 * C, c->v_mean, c->v_rstd, 1), nullptr, view(c->S_l, 4, 0, 4), c->R_c, B, st);
@@ -443,7 +460,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
             ms[c->ev_kind[i]] += t;
             n[c->ev_kind[i]]++;
         }
-        ms[0] = ms[2] + ms[4]; n[0] = n[2] + n[4]; c->prof_work[0] = c->prof_work[2] + c->prof_work[4];
+        ms[0] = ms[2] + ms[4] + ms[5]; n[0] = n[2] + n[4] + n[5]; c->prof_work[0] = c->prof_work[2] + c->prof_work[4] + c->prof_work[5];
         for (int k = 0; k < PROF_KINDS; ++k) { c->last_ms[k] = ms[k]; c->last_launches[k] = n[k]; c->last_work[k] = c->prof_work[k]; }
     }
     return MICA_OK;
@@ -541,6 +558,7 @@ int mica_create(int device, int max_batch, int tile_size, mica_ctx** out) {
         return MICA_ERR_HIP;
     }
     mica_ctx* c = new mica_ctx();
+    if (const char* ev = getenv("MICA_F43")) c->f43_mode = atoi(ev) != 0;      // A/B switch (0: the F(2,3) kernel everywhere)
     c->device = device;
     c->maxB = max_batch;
     c->S = tile_size;
@@ -608,6 +626,16 @@ int mica_load_weight(mica_ctx* c, const char* name, const float* h_data, const i
     return MICA_OK;
 }
 
+int mica_set_conv_variant(mica_ctx* c, int mode) {
+    if (!c) return MICA_ERR_ARG;
+    if (mode != 0 && mode != 1) { c->err = "mica_set_conv_variant: mode must be 0 or 1"; return MICA_ERR_ARG; }
+    if (c->finalized) { c->err = "mica_set_conv_variant: weights already finalized (the variant decides how they are packed)"; return MICA_ERR_STATE; }
+    c->f43_mode = mode;
+    return MICA_OK;
+}
+
+int mica_get_conv_variant(const mica_ctx* c) { return c ? c->f43_mode : MICA_ERR_ARG; }
+
 int mica_finalize_weights(mica_ctx* c) {
     if (!c) return MICA_ERR_ARG;
     if (c->finalized) { c->err = "already finalized"; return MICA_ERR_STATE; }
@@ -653,13 +681,16 @@ int mica_finalize_weights(mica_ctx* c) {
         const int C = 64 << e;
         E.C = C;
         const std::string p = "encoder." + std::to_string(e) + ".";
-        if ((r = setup_conv(c, E.conv1, p + "dense_block.conv1.0", C / 2, 3, {C}, false))) return r;
-        if ((r = setup_conv(c, E.conv2, p + "dense_block.conv2.0", C / 2, 3, {C, C / 2}, false))) return r;
-        if ((r = setup_conv(c, E.conv3, p + "dense_block.conv3.0", C, 3, {C, C / 2, C / 2}, false))) return r;
+        // all four 3^3 convs of an encoder switch together (they share operands): encoder.2 has Cout = 128, 128, 256, 512
+        const bool f43 = c->f43_mode == 1 && e == 2;
+        if ((r = setup_conv(c, E.conv1, p + "dense_block.conv1.0", C / 2, 3, {C}, false, 1.f, f43))) return r;
+        if ((r = setup_conv(c, E.conv2, p + "dense_block.conv2.0", C / 2, 3, {C, C / 2}, false, 1.f, f43))) return r;
+        if ((r = setup_conv(c, E.conv3, p + "dense_block.conv3.0", C, 3, {C, C / 2, C / 2}, false, 1.f, f43))) return r;
         if ((r = setup_gate(c, E.se, p + "dense_block.se.fc.0", p + "dense_block.se.fc.3", C, C / 16, true))) return r;
         if ((r = setup_gate(c, E.ga, p + "dual_attn.global_attn.1", p + "dual_attn.global_attn.4", C, C / 4, false))) return r;
         if ((r = setup_conv(c, E.fusion, p + "dual_attn.fusion", C, 1, {C, C}, true))) return r;
-        if ((r = setup_conv(c, E.transition, p + "transition.0", 2 * C, 3, {C}, false))) return r;
+        if ((r = setup_conv(c, E.transition, p + "transition.0", 2 * C, 3, {C}, false, 1.f, f43))) return r;
+        if (E.conv1.f43 != E.conv2.f43 || E.conv1.f43 != E.conv3.f43 || E.conv1.f43 != E.transition.f43) { c->err = "internal: mixed conv variants in an encoder"; return MICA_ERR_STATE; }
         const HostTensor *dw = find(c, p + "dual_attn.local_attn.0.weight"), *db = find(c, p + "dual_attn.local_attn.0.bias");
         if (!shape_is(dw, {C, 1, 3, 3, 3}) || !shape_is(db, {C})) { c->err = "depthwise weights missing or mis-shaped"; return MICA_ERR_STATE; }
         std::vector<float> wt((size_t)27 * C);
@@ -950,23 +981,30 @@ int mica_neighbour_matrix_np(mica_ctx* c, const double* d_cands, int64_t n, cons
 // ---- single-op entry points (test harness for the individual kernels) ---------------------------
 int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w, const float* h_b,
                    int cout, int k, float* d_y, void* stream) {
+    return mica_op_conv3d_variant(c, d_x, batch, cin, d, h, w, h_w, h_b, cout, k, 0, d_y, stream);
+}
+
+int mica_op_conv3d_variant(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w, const float* h_b,
+                           int cout, int k, int variant, float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
     if (!d_x || !h_w || !h_b || !d_y || batch < 1 || cin < 1 || cout < 32 || cout % 32 || (k != 1 && k != 3) || d < 1 || h < 1 || w < 1 ||
-        (k == 1 && cout != 64 && cout != 128 && cout != 256)) {
-        c->err = "mica_op_conv3d: bad argument (k = 3: cout a multiple of 32; k = 1: cout in {64, 128, 256})";
+        (k == 1 && cout != 64 && cout != 128 && cout != 256) || variant < 0 || variant > 1 || (variant == 1 && (k != 3 || cout % 128))) {
+        c->err = "mica_op_conv3d: bad argument (k = 3: cout a multiple of 32, of 128 for the F(4,3) variant; k = 1: cout in {64, 128, 256})";
         return MICA_ERR_ARG;
     }
+    const bool f43 = variant == 1;
     HIPC(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const int V = d * h * w, cp = pad16(cin), nt = k * k * k;
     const bool wino = (k == 3);
-    const int64_t Vop = wino ? (int64_t)d * h * ((w + 1) / 2) * 4 : V;
+    const int64_t Vop = f43 ? (int64_t)d * h * ((w + 3) / 4) * 6 : wino ? (int64_t)d * h * ((w + 1) / 2) * 4 : V;
     Tmp t;
     _Float16* sx = t.get<_Float16>((int64_t)batch * Vop * cp * 2);
     float* dw = t.get<float>((int64_t)cout * cin * nt);
     float* db = t.get<float>(cout);
     float* raw = t.get<float>((int64_t)batch * V * cout);
-    _Float16* pk = t.get<_Float16>(wino ? packed_weight_halves_wino(cout, cp / 16) : packed_weight_halves(cout, k, cp / 16));
+    _Float16* pk = t.get<_Float16>(f43 ? packed_weight_halves_wino43(cout, cp / 16)
+                                       : wino ? packed_weight_halves_wino(cout, cp / 16) : packed_weight_halves(cout, k, cp / 16));
     int* derr = t.get<int>(1);
     if (!sx || !dw || !db || !raw || !pk || !derr) { c->err = "mica_op_conv3d: hipMalloc failed"; return MICA_ERR_HIP; }
     std::vector<float> hw(h_w, h_w + (size_t)cout * cin * nt);
@@ -977,7 +1015,12 @@ int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int
     int sc[1] = {cin}, scp[1] = {cp};
     ConvSrcs s{};
     s.n = 1; s.p[0] = sx; s.chunks_total[0] = cp / 16; s.chunk_off[0] = 0; s.chunks[0] = cp / 16;
-    if (wino) {
+    if (f43) {
+        const float asc = ASCALE_DEFAULT / WINO43_ASCALE_DIV;
+        launch_prep_ncdhw_wino43(d_x, batch, Dims{d, h, w}, cin, SplitView{sx, cp / 16, 0, cp / 16}, SplitEnc{derr, asc}, st);
+        launch_pack_weights_wino43(dw, cout, cin, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
+        launch_conv_wino43(s, pk, 0, db, 1.0f / (ws * asc), raw, batch, Dims{d, h, w}, cout, nullptr, st);
+    } else if (wino) {
         launch_prep_ncdhw_wino(d_x, batch, Dims{d, h, w}, cin, SplitView{sx, cp / 16, 0, cp / 16}, SplitEnc{derr, ASCALE_DEFAULT}, st);
         launch_pack_weights_wino(dw, cout, cin, sc, scp, 1, nullptr, 1, 1.f, ws, pk, st);
         launch_conv_wino(s, pk, 0, db, 1.0f / (ws * ASCALE_DEFAULT), raw, batch, Dims{d, h, w}, cout, nullptr, st);
@@ -998,9 +1041,15 @@ int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int
 
 int mica_op_norm_conv1_conv3(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w1, const float* h_b1,
                              int cmid, const float* h_w3, const float* h_b3, int cout, float* d_y, void* stream) {
+    return mica_op_norm_conv1_conv3_variant(c, d_x, batch, cin, d, h, w, h_w1, h_b1, cmid, h_w3, h_b3, cout, 0, d_y, stream);
+}
+
+int mica_op_norm_conv1_conv3_variant(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w1, const float* h_b1,
+                                     int cmid, const float* h_w3, const float* h_b3, int cout, int variant, float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
+    const bool f43 = variant == 1;
     if (!d_x || !h_w1 || !h_b1 || !h_w3 || !h_b3 || !d_y || batch < 1 || cin < 16 || !pow2_8_512(cin) || (cmid != 64 && cmid != 128 && cmid != 256) ||
-        cout < 32 || cout % 32 || d < 1 || h < 1 || w < 1) {
+        cout < 32 || cout % 32 || d < 1 || h < 1 || w < 1 || variant < 0 || variant > 1 || (f43 && cout % 128)) {
         c->err = "mica_op_norm_conv1_conv3: bad argument (cin a power of two in [16,512], cmid in {64,128,256}, cout a multiple of 32)";
         return MICA_ERR_ARG;
     }
@@ -1008,7 +1057,7 @@ int mica_op_norm_conv1_conv3(mica_ctx* c, const float* d_x, int batch, int cin, 
     hipStream_t st = (hipStream_t)stream;
     const Dims dm{d, h, w};
     const int V = d * h * w;
-    const int64_t Vw = (int64_t)d * h * ((w + 1) / 2) * 4;
+    const int64_t Vw = f43 ? (int64_t)d * h * ((w + 3) / 4) * 6 : (int64_t)d * h * ((w + 1) / 2) * 4;
     Tmp t;
     float* xr = t.get<float>((int64_t)batch * V * cin);              // raw NDHWC input
     float* mean = t.get<float>((int64_t)batch * cin);
@@ -1022,7 +1071,7 @@ int mica_op_norm_conv1_conv3(mica_ctx* c, const float* d_x, int batch, int cin, 
     float* dw3 = t.get<float>((int64_t)cout * cmid * 27);
     float* db3 = t.get<float>(cout);
     _Float16* pk1 = t.get<_Float16>(packed_weight_halves(cmid, 1, cin / 16));
-    _Float16* pk3 = t.get<_Float16>(packed_weight_halves_wino(cout, cmid / 16));
+    _Float16* pk3 = t.get<_Float16>(f43 ? packed_weight_halves_wino43(cout, cmid / 16) : packed_weight_halves_wino(cout, cmid / 16));
     int* derr = t.get<int>(1);
     if (!xr || !mean || !rstd || !ws || !mid || !op || !raw || !dw1 || !db1 || !dw3 || !db3 || !pk1 || !pk3 || !derr) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
     std::vector<float> v1(h_w1, h_w1 + (size_t)cmid * cin), v3(h_w3, h_w3 + (size_t)cout * cmid * 27);
@@ -1037,20 +1086,24 @@ int mica_op_norm_conv1_conv3(mica_ctx* c, const float* d_x, int batch, int cin, 
     launch_stats(xr, batch, V, cin, 1e-5f, mean, rstd, ws, st);
     int sc1[1] = {cin}, sc3[1] = {cmid};
     launch_pack_weights(dw1, cmid, cin, 1, sc1, sc1, 1, nullptr, 1, 1.f, s1, pk1, st);
-    launch_pack_weights_wino(dw3, cout, cmid, sc3, sc3, 1, nullptr, 1, 1.f, s3, pk3, st);
+    if (f43) launch_pack_weights_wino43(dw3, cout, cmid, sc3, sc3, 1, nullptr, 1, 1.f, s3, pk3, st);
+    else launch_pack_weights_wino(dw3, cout, cmid, sc3, sc3, 1, nullptr, 1, 1.f, s3, pk3, st);
     Conv1Srcs s{};
     s.n = 1;
     s.s[0] = Conv1Src{xr, mean, rstd, 1, cin / 16, cin / 16, 0, 1};
     const SplitView opv{op, cmid / 16, 0, cmid / 16};
-    if (conv1x1_can_emit_wino(dm)) {
-        launch_conv1x1(s, pk1, 0, db1, 1.0f / (s1 * ASCALE_DEFAULT), nullptr, opv, batch, dm, cmid, enc, st);
+    const float asc3 = f43 ? ASCALE_DEFAULT / WINO43_ASCALE_DIV : ASCALE_DEFAULT;
+    if (conv1x1_can_emit_wino(dm, f43 ? 2 : 1)) {
+        launch_conv1x1(s, pk1, 0, db1, 1.0f / (s1 * ASCALE_DEFAULT), nullptr, opv, batch, dm, cmid, enc, st, f43 ? 2 : 1, asc3);
     } else {
         launch_conv1x1(s, pk1, 0, db1, 1.0f / (s1 * ASCALE_DEFAULT), mid, SplitView{nullptr, 0, 0, 0}, batch, dm, cmid, enc, st);
-        launch_prep_wino(mid, batch, dm, cmid, nullptr, nullptr, 0, nullptr, opv, SplitView{nullptr, 0, 0, 0}, nullptr, ws, enc, st);
+        if (f43) launch_prep_wino43(mid, batch, dm, cmid, nullptr, nullptr, 0, opv, SplitEnc{derr, asc3}, st);
+        else launch_prep_wino(mid, batch, dm, cmid, nullptr, nullptr, 0, nullptr, opv, SplitView{nullptr, 0, 0, 0}, nullptr, ws, enc, st);
     }
     ConvSrcs cs{};
     cs.n = 1; cs.p[0] = op; cs.chunks_total[0] = cmid / 16; cs.chunk_off[0] = 0; cs.chunks[0] = cmid / 16;
-    launch_conv_wino(cs, pk3, 0, db3, 1.0f / (s3 * ASCALE_DEFAULT), raw, batch, dm, cout, nullptr, st);
+    if (f43) launch_conv_wino43(cs, pk3, 0, db3, 1.0f / (s3 * asc3), raw, batch, dm, cout, nullptr, st);
+    else launch_conv_wino(cs, pk3, 0, db3, 1.0f / (s3 * ASCALE_DEFAULT), raw, batch, dm, cout, nullptr, st);
     launch_nhwc_to_nchw(raw, batch, cout, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));

@@ -53,10 +53,11 @@ __device__ __forceinline__ void c1_split8(const float (&y)[8], half8& hi, half8&
     mica_split8(y, hi, lo, bad, ascale);
 }
 
-template <int NCT, bool WINO>
+// WINO: 0 = raw f32 output, 1 = the F(2,3) operand, 2 = the F(4,3) operand (kernels_conv43.hip), encoded at out_ascale
+template <int NCT, int WINO>
 __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x1_kernel(Conv1Srcs src, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
                                                       const float* __restrict__ bias, float out_scale, float* __restrict__ out_raw,
-                                                      SplitView wino, Dims d, int cout, int total_chunks, SplitEnc enc) {
+                                                      SplitView wino, Dims d, int cout, int total_chunks, SplitEnc enc, float out_ascale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* tab = reinterpret_cast<float2*>(smem + C1_LDS - C1_TAB);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
                     T[(f * 16 + lg * 4 + i) * C1_TS + wn * 16 + lr] = acc[f][pass][i] * out_scale + bv;
         }
         __syncthreads();
-        if (!WINO) {
+        if (WINO == 0) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int id = it * C1_NT + tid, cg = id & 15, row = id >> 4;
@@ -237,6 +238,50 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
                 if (v < V)
                     *reinterpret_cast<float4*>(out_raw + ((int64_t)b * V + v) * cout + pass * 64 + cg * 4) =
                         *reinterpret_cast<const float4*>(T + row * C1_TS + cg * 4);
+            }
+        } else if (WINO == 2) {
+            // F(4,3) input transform of the consumer (kernels_conv43.hip: prep_wino43_kernel): per output quad (x = 4i .. 4i+3) and
+            // d_k = y(4i-1+k), k = 0..5, zero outside the row; 32 quads x 8 channel groups = one task per thread
+            const int Wq = (d.W + 3) >> 2, Vq = d.D * d.H * Wq;
+            {
+                const int phl = tid & 31, kg = tid >> 5;
+                const int yr = phl / Wq, i = phl - yr * Wq;
+                const int vrow = v0 + yr * d.W;       // first voxel of this x row
+                if (vrow < V) {
+                    float dv[6][8];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int xx = 4 * i - 1 + k;
+                        const bool ok = (unsigned)xx < (unsigned)d.W;
+                        const float* tp = T + (yr * d.W + (ok ? xx : 0)) * C1_TS + kg * 8;
+                        const float4 a = *reinterpret_cast<const float4*>(tp), c = *reinterpret_cast<const float4*>(tp + 4);
+                        dv[k][0] = ok ? a.x : 0.f; dv[k][1] = ok ? a.y : 0.f; dv[k][2] = ok ? a.z : 0.f; dv[k][3] = ok ? a.w : 0.f;
+                        dv[k][4] = ok ? c.x : 0.f; dv[k][5] = ok ? c.y : 0.f; dv[k][6] = ok ? c.z : 0.f; dv[k][7] = ok ? c.w : 0.f;
+                    }
+                    float t[6][8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float d0 = dv[0][j], d1 = dv[1][j], d2 = dv[2][j], d3 = dv[3][j], d4 = dv[4][j], d5 = dv[5][j];
+                        t[0][j] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+                        const float e = fmaf(-4.f, d2, d4), o = fmaf(-4.f, d1, d3);
+                        t[1][j] = e + o;
+                        t[2][j] = e - o;
+                        const float e2 = d4 - d2, o2 = 2.f * (d3 - d1);
+                        t[3][j] = e2 + o2;
+                        t[4][j] = e2 - o2;
+                        t[5][j] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+                    }
+                    const int chunk = pass * 4 + (kg >> 1), kh = kg & 1;
+                    const int64_t ph = (int64_t)(vrow / d.W) * Wq + i;
+                    _Float16* wbp = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + chunk) * (int64_t)Vq) * 192;
+#pragma unroll
+                    for (int pp = 0; pp < 6; ++pp) {
+                        half8 hi, lo;
+                        c1_split8(t[pp], hi, lo, bad2, out_ascale);
+                        *reinterpret_cast<half8*>(wbp + ((int64_t)(pp * 4 + kh) * Vq + ph) * 8) = hi;
+                        *reinterpret_cast<half8*>(wbp + ((int64_t)(pp * 4 + 2 + kh) * Vq + ph) * 8) = lo;
+                    }
+                }
             }
         } else {
             // Winograd input transform of the consumer (kernels_elem.hip: prep_wino_kernel): per output pair (x = 2i, 2i+1) and
@@ -271,7 +316,7 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
 #pragma unroll
                     for (int pp = 0; pp < 4; ++pp) {
                         half8 hi, lo;
-                        c1_split8(t[pp], hi, lo, bad2, enc.ascale);
+                        c1_split8(t[pp], hi, lo, bad2, out_ascale);
                         *reinterpret_cast<half8*>(wbp + ((int64_t)(pp * 4 + kh) * Vh + ph) * 8) = hi;
                         *reinterpret_cast<half8*>(wbp + ((int64_t)(pp * 4 + 2 + kh) * Vh + ph) * 8) = lo;
                     }
@@ -283,11 +328,14 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
 }
 
 
-bool conv1x1_can_emit_wino(Dims d) { return d.W >= 2 && d.W <= 64 && C1_ROWS % d.W == 0 && (d.W & 1) == 0; }
+bool conv1x1_can_emit_wino(Dims d, int wino_kind) {
+    const int m = wino_kind == 2 ? 4 : 2;          // whole x rows per workgroup and whole output pairs / quads per row
+    return d.W >= m && d.W <= 64 && C1_ROWS % d.W == 0 && d.W % m == 0;
+}
 
-template <int NCT, bool WINO>
+template <int NCT, int WINO>
 static void launch_conv1x1_t(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
-                             float* out_raw, SplitView wino, int B, Dims d, int cout, int total, SplitEnc enc, hipStream_t st) {
+                             float* out_raw, SplitView wino, int B, Dims d, int cout, int total, SplitEnc enc, float out_ascale, hipStream_t st) {
     static unsigned long long seen = 0;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !(seen >> dev & 1ull)) {
@@ -297,12 +345,13 @@ static void launch_conv1x1_t(const Conv1Srcs& src, const _Float16* wpk, int64_t 
     const int V = d.D * d.H * d.W;
     dim3 grid((V + C1_ROWS - 1) / C1_ROWS, B);
     hipLaunchKernelGGL((conv1x1_kernel<NCT, WINO>), grid, dim3(C1_NT), C1_LDS, st, src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, d, cout,
-                       total, enc);
+                       total, enc, out_ascale);
 }
 
 // cout in {64, 128, 256}.  Exactly one of out_raw / wino.p is given; wino needs conv1x1_can_emit_wino(d).
 void launch_conv1x1(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out_raw,
-                    SplitView wino, int B, Dims d, int cout, SplitEnc enc, hipStream_t st) {
+                    SplitView wino, int B, Dims d, int cout, SplitEnc enc, hipStream_t st, int wino_kind, float enc_out_ascale) {
+    const float oasc = enc_out_ascale > 0.f ? enc_out_ascale : enc.ascale;
     int total = 0;
     for (int i = 0; i < src.n; ++i) {
         total += src.s[i].chunks;
@@ -310,11 +359,12 @@ void launch_conv1x1(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstri
         // forward graph and checked by the single-op entry points
         if (src.s[i].kind == 1 && src.s[i].chunks_total * 16 > 512) { fprintf(stderr, "conv1x1: raw source wider than 512 channels\n"); abort(); }
     }
-    const bool w = wino.p != nullptr;
-#define C1_GO(NCT)                                                                                                          \
-    do {                                                                                                                    \
-        if (w) launch_conv1x1_t<NCT, true>(src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, B, d, cout, total, enc, st);  \
-        else launch_conv1x1_t<NCT, false>(src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, B, d, cout, total, enc, st);   \
+    const int w = wino.p != nullptr ? (wino_kind == 2 ? 2 : 1) : 0;
+#define C1_GO(NCT)                                                                                                                      \
+    do {                                                                                                                                \
+        if (w == 2) launch_conv1x1_t<NCT, 2>(src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, B, d, cout, total, enc, oasc, st);    \
+        else if (w == 1) launch_conv1x1_t<NCT, 1>(src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, B, d, cout, total, enc, oasc, st); \
+        else launch_conv1x1_t<NCT, 0>(src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, B, d, cout, total, enc, oasc, st);           \
     } while (0)
     if (cout == 64) C1_GO(1);
     else if (cout == 128) C1_GO(2);

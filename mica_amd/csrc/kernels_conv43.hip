@@ -1,0 +1,629 @@
+// Dense 3x3x3 convolution with Winograd F(4,3) along x for the layers where the whole-network numerics allow it (round 4).
+//
+// conv_wino16_kernel<128> (kernels_conv.hip, F(2,3) along x) is power-bound on the matrix pipes: the only lever on its time is
+// fewer MFMAs per output.  F(4,3) needs 6 transform-domain products per 4 outputs instead of 4 per 2: 13.5 instead of 18
+// MFMA-taps per output (1.33x fewer), and its operand is 1.5x the plain bytes instead of 2x.  Its transforms have constants up to
+// 8, so a layer's rounding error is about 4x that of F(2,3); oracle/wino_network.py (whole-network emulation of exactly this
+// arithmetic, profiles/r04_wino_network_numerics.txt) shows where that matters: F(4,3) EVERYWHERE doubles the network's rms
+// distance from the float64 truth and breaks the 1e-4 bar, on all layers with Cout >= 128 it is borderline, but on the four
+// 3x3x3 convs of encoder.2 (conv1 256->128, conv2 384->128, conv3 512->256, transition 256->512: 68 % of the network's FLOPs, K =
+// 27 x 256..512 per output, late in the network) the result is indistinguishable from F(2,3) everywhere.  Those four layers run here.
+// Replaces nn.Conv3d(k=3, padding=1) of reference models/model.py:107,115,122,142 (encoder.2).
+//
+//   points {0, 1, -1, 2, -2, inf}; per output quad (x = 4i .. 4i+3), d_k = in(4i-1+k), k = 0..5 (zero outside the volume):
+//     t0 = 4 d0 - 5 d2 + d4            u0 = g0/4                               y0 = m0 + m1 + m2 +  m3 +  m4
+//     t1 = -4 d1 - 4 d2 + d3 + d4      u1 = -(g0 + g1 + g2)/6                  y1 =      m1 - m2 + 2m3 - 2m4
+//     t2 =  4 d1 - 4 d2 - d3 + d4      u2 = -(g0 - g1 + g2)/6                  y2 =      m1 + m2 + 4m3 + 4m4
+//     t3 = -2 d1 -   d2 + 2 d3 + d4    u3 = g0/24 + g1/12 + g2/6               y3 =      m1 - m2 + 8m3 - 8m4 + m5
+//     t4 =  2 d1 -   d2 - 2 d3 + d4    u4 = g0/24 - g1/12 + g2/6               m_p = sum over (dz, dy, cin) of t_p u_p
+//     t5 =  4 d1 - 5 d3 + d5           u5 = g2
+//   The producer passes (prep_wino43_kernel below, the F(4,3) epilogue of conv1x1_kernel) do the input transform in f32 and
+//   encode t * (ascale / 4) as f16 hi + lo (|t| <= 10 max|d|: a quarter of the scale keeps the f16 range of the F(2,3) operand
+//   to within 2.5x; powers of two, exact); the weight packer does the weight transform in f64.
+//
+// Operand ("wino43") layout:  _Float16 [B][chunks][6 p][4 q][Vq][8],  Vq = D*H*ceil(W/4); q = hi|lo x channel half of the chunk.
+//
+// Kernel structure = conv_wino16_kernel<128> re-dimensioned (same MFMA shape v_mfma_f32_16x16x32_f16, same regrouping of the three
+// split products into X / X' / Y steps over tap pairs, same persistent item walk, slab LDS-DMA with counted vmcnt, asm weight
+// prefetch): workgroup = 12 waves = 6 positions x 2 channel halves; output tile 16(x) = 4 quads x 4(y) x 4(z); wave (p, wn) owns
+// Winograd position p for all 64 (quad, y, z) rows and 64 channels = 4 row fragments (one per z: 4 quads x 4 y) x 4 column tiles
+// = 64 accumulator VGPRs, three waves per SIMD.  LDS image per chunk: 4 planes (hi/lo x k-half) x [z 6][p 6][y 6][quad 4] 16-B
+// slots = 55,296 B, double buffered.  Per chunk and workgroup 2,688 MFMAs instead of 3,584 for the same 256 voxels x 128
+// channels; a weight fragment feeds 4 MFMAs (8 in the F(2,3) kernel: the weight stream from L2 is 1.5x per output).
+#include "common.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace mica {
+
+struct Segs43 { int c[MAX_SRC]; int cp[MAX_SRC]; int n; };
+
+struct Geo43 {
+    static constexpr int SY = 6, SZ = 6, NP = 6, QX = 4;
+    static constexpr int PP = SY * QX;                 // 24 slots per (z, p)
+    static constexpr int PZ = NP * PP;                 // 144 slots per z plane
+    static constexpr int PLANE = SZ * PZ;              // 864 slots per (hi/lo, k-half) plane
+    static constexpr int NSLOT = 4 * PLANE;            // 3456
+    static constexpr int CH_BYTES = NSLOT * 16;        // 55,296
+    static constexpr int NDMA = NSLOT / 64;            // 54 one-KiB LDS-DMA instructions per chunk
+    static constexpr int NW = 12;                      // waves per workgroup
+    static constexpr int DPW = 5;                      // DMA slots per wave and chunk (12 x 5 = 60 >= 54; the last six are no-ops)
+    static constexpr int BN = 128;
+};
+static_assert(Geo43::NSLOT % 64 == 0 && Geo43::NDMA <= Geo43::NW * Geo43::DPW, "slab DMA plan");
+
+typedef float floatx4w __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ constexpr int w43_step_ps(int st) { return st < 12 ? st / 3 : 4; }
+__device__ __forceinline__ constexpr int w43_step_kind(int st) { return st < 12 ? st % 3 : (st - 12) * 2; }   // 0 Y, 1 X' (second tap), 2 X (first tap)
+
+__device__ __forceinline__ const _Float16* chunk_base_wino43(const ConvSrcs& s, int gch, int b, int Vq) {
+    int si = 0, ch = gch;
+#pragma unroll
+    for (int i = 0; i < MAX_SRC - 1; ++i)
+        if (si == i && i + 1 < s.n && ch >= s.chunks[i]) { ch -= s.chunks[i]; si = i + 1; }
+    return s.p[si] + ((int64_t)b * s.chunks_total[si] + s.chunk_off[si] + ch) * (int64_t)Vq * 192;
+}
+
+__global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
+                                                          const float* __restrict__ bias, float out_scale, float* __restrict__ out,
+                                                          Dims d, int cout, int total_chunks, int ntx, int nty, int nnb,
+                                                          int items_per_b, int total_items, float* __restrict__ stats_ws) {
+    using G = Geo43;
+    constexpr int BN = G::BN, NCT = 4, NS = 14, NF = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave % 6, wn = wave / 6;
+    const int Wq = (d.W + 3) >> 2;
+    const int V = d.D * d.H * d.W, Vq = d.D * d.H * Wq;
+
+    // persistent schedule (as conv_wino16_kernel): workgroup g sits on XCD g & 7, each XCD takes a contiguous eighth of the items
+    const int xcd = blockIdx.x & 7, lwg = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int range = (total_items + 7) >> 3;
+    const int it_end = min(total_items, (xcd + 1) * range);
+    int item = xcd * range + lwg;
+    if (item >= it_end) return;
+
+    // A operand: lane = (row r = lane & 15 -> quad r & 3, y r >> 2 ; k-group g = lane >> 4); a fragment is one z plane of the tile
+    const int lr = lane & 15, lg = lane >> 4;
+    const int himask = (lg >> 1) ? -1 : 0;
+    const int a_common = ((lg & 1) * G::PLANE + wp * G::PP + lr) * 16;
+
+    // packed weights: [nb][chunk][pair-step 5][p 6][unit 8][128 cout][8 halves]; units: 0,1 hi(t) k-half 0,1 | 2,3 hi(t') | 4,5 lo(t) | 6,7 lo(t')
+    constexpr int ustride = BN * 16;
+    constexpr int psstride = 6 * 8 * ustride;               // 98,304
+    constexpr int chstride = 5 * psstride;                  // 491,520
+    const unsigned w_common = (unsigned)((lg & 1) * BN + lr) * 16u;
+    const int64_t nbstride = (int64_t)total_chunks * chstride;
+    const char* wwave = reinterpret_cast<const char*>(wpk) + wp * 8 * ustride + wn * 64 * 16;
+
+    half8 bq[2][NCT];
+#define W43_TAP(st) (2 * w43_step_ps(st) + (w43_step_kind(st) == 1 ? 1 : 0))
+#define W43_AOFF(st) (((W43_TAP(st) / 3) * G::PZ + (W43_TAP(st) % 3) * G::QX) * 16)
+#define W43_ADELTA(st) (w43_step_kind(st) != 0 ? 2 * G::PLANE * 16 : (w43_step_ps(st) == 1 ? (G::PZ - 2 * G::QX) * 16 : G::QX * 16))
+#define W43_WOFF(st) (w43_step_ps(st) * psstride + (w43_step_kind(st) == 0 ? 4 : w43_step_kind(st) == 1 ? 2 : 0) * ustride)
+#define W43_WDELTA(st) (w43_step_kind(st) == 0 ? 2 * BN * 16 : 0)
+#define MICA_BLOAD43(set, wbase, ls)                                                                                    \
+    do {                                                                                                                \
+        const char* pb_ = (wbase) + W43_WOFF(ls);                                                                       \
+        const unsigned vo_ = w_common + (unsigned)(W43_WDELTA(ls) & himask);                                            \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][0]) : "v"(vo_), "s"(pb_) : "memory");              \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(bq[set][1]) : "v"(vo_), "s"(pb_) : "memory");   \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(bq[set][2]) : "v"(vo_), "s"(pb_) : "memory");   \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:768" : "=v"(bq[set][3]) : "v"(vo_), "s"(pb_) : "memory");   \
+    } while (0)
+
+    // Slab DMA instruction k of this wave covers the 64 consecutive slots starting at (k * 12 + wave) * 64 of the flat LDS image
+    // [q 4][z 6][p 6][y 6][quad 4].  Issued UNCONDITIONALLY (lanes outside the volume masked by hand and zeroed explicitly; the
+    // slots 54..59 of the plan do not exist and are issued with every lane masked), so that the number of vector-memory operations
+    // in flight is a compile-time fact and the weight waits can leave the newest DMA outstanding.
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    int rel[G::DPW], meta[G::DPW];      // global byte offset within a chunk relative to the slab origin ; vy | vz << 3 | exists << 6
+#pragma unroll
+    for (int k = 0; k < G::DPW; ++k) {
+        const int ii = k * G::NW + wave;
+        const int slot = ii * 64 + lane;
+        const int q = slot / G::PLANE, rem = slot - q * G::PLANE;
+        const int vz = rem / G::PZ, r2 = rem - vz * G::PZ;
+        const int pp = r2 / G::PP, r3 = r2 - pp * G::PP;
+        const int vy = r3 >> 2, quad = r3 & 3;
+        rel[k] = ((pp * 4 + q) * Vq + (vz * d.H + vy) * Wq + quad) * 16;
+        meta[k] = vy | (vz << 3) | ((ii < G::NDMA ? 1 : 0) << 6);
+    }
+#define MICA_SLAB_DMA43(srcbase, bufoff, k, org)                                                                        \
+    do {                                                                                                                \
+        const int lo_ = (bufoff) + (((k) * G::NW + wave) * 64) * 16;                                                    \
+        const unsigned la_ = __builtin_amdgcn_readfirstlane(lds0 + lo_);                                                \
+        const bool ex_ = (meta[k] >> 6) != 0;                                                                           \
+        const bool ok_ = ex_ && (org).i0 + (lane & 3) < Wq && (unsigned)((org).y0 + (meta[k] & 7)) < (unsigned)d.H &&   \
+                         (unsigned)((org).z0 + ((meta[k] >> 3) & 7)) < (unsigned)d.D;                                   \
+        const int go_ = ok_ ? (org).base + rel[k] : -1;                                                                 \
+        unsigned long long sv_;                                                                                         \
+        asm volatile("s_mov_b64 %0, exec\n\tv_cmp_lt_i32 vcc, -1, %1\n\ts_mov_b64 exec, vcc\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" \
+                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                                              \
+                     : "=&s"(sv_) : "v"(go_), "s"(srcbase), "s"(la_) : "memory", "vcc", "m0");                           \
+        if (ex_ && !ok_) *reinterpret_cast<uint4*>(smem + lo_ + lane * 16) = make_uint4(0, 0, 0, 0);                    \
+    } while (0)
+
+    struct Item {
+        int b, nb, tile;
+        int i0, y0, z0, base;          // slab origin: first x quad, y, z (halo included) and its byte offset in a chunk
+        const char* w;                 // this wave's weights of chunk 0
+        const _Float16* src0;          // chunk 0 of the operand
+    };
+    auto decode = [&](int it) {
+        Item r;
+        r.b = it / items_per_b;
+        const int id = it - r.b * items_per_b;
+        r.nb = id % nnb;
+        const int seq = id / nnb;
+        int tx, ty, tz;
+        if (((nty & 7) | (((d.D + 3) >> 2) & 3)) == 0) {       // compact 8(y) x 4(z) blocks of tiles per XCD round (shared y/z halos in L2)
+            const int inb = seq & 31, blk = seq >> 5, nby = nty >> 3;
+            tx = blk % ntx;
+            ty = (blk / ntx % nby) * 8 + (inb & 7);
+            tz = (blk / (ntx * nby)) * 4 + (inb >> 3);
+        } else {
+            tx = seq % ntx;
+            ty = seq / ntx % nty;
+            tz = seq / (ntx * nty);
+        }
+        r.tile = (tz * nty + ty) * ntx + tx;
+        r.i0 = tx * 4;
+        r.y0 = ty * 4 - 1;
+        r.z0 = tz * 4 - 1;
+        r.base = ((r.z0 * d.H + r.y0) * Wq + r.i0) * 16;
+        r.w = wwave + (int64_t)r.b * wpk_bstride * 2 + r.nb * nbstride;
+        r.src0 = chunk_base_wino43(s, 0, r.b, Vq);
+        return r;
+    };
+    const int64_t chunk_halves = (int64_t)Vq * 192;
+
+    Item cur = decode(item);
+    int nitem = item + per_xcd;
+    Item nxt = decode(nitem < it_end ? nitem : item);
+
+#define W43_SET(ls) ((ls) & 1)
+#define W43_NDMA(ls) ((ls) < G::DPW ? 1 : 0)
+    // prologue of the first item: slab chunk 0 -> buffer 0, weights of the wave's first step
+    MICA_BLOAD43(W43_SET(0), cur.w, 0);
+#pragma unroll
+    for (int k = 0; k < G::DPW; ++k) MICA_SLAB_DMA43(cur.src0, 0, k, cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int par = 0;
+
+    for (;;) {
+        const bool has_next = nitem < it_end;
+        floatx4w acc[NF][NCT];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[f][c][i] = 0.f;
+
+        const _Float16* run = cur.src0;
+        int si = 0, left = s.chunks[0];
+        const char* wcur = cur.w;
+#pragma clang loop unroll(disable)
+        for (int gch = 0; gch < total_chunks; ++gch) {
+            const char* A = smem + par * G::CH_BYTES;
+            const int nxt_off = (par ^ 1) * G::CH_BYTES;
+            const bool last = gch + 1 == total_chunks;
+            if (!last) {
+                if (--left == 0) {
+                    ++si;
+                    left = s.chunks[si];
+                    run = s.p[si] + ((int64_t)cur.b * s.chunks_total[si] + s.chunk_off[si]) * chunk_halves;
+                } else {
+                    run += chunk_halves;
+                }
+            }
+            const _Float16* nsrc = last ? nxt.src0 : run;        // the last chunk's DMAs fetch the NEXT item's first slab
+            Item org = cur;
+            if (last) org = nxt;
+            const char* wnxt = last ? nxt.w : wcur + chstride;
+#define W43_ABASE(ls) (A + a_common + (W43_ADELTA(ls) & himask) + W43_AOFF(ls))
+#define W43_AFRAG(base, f) (*reinterpret_cast<const half8*>((base) + (f) * G::PZ * 16))
+            const char* ab_cur = W43_ABASE(0);
+            constexpr int AD = 3;
+            half8 ar[AD + 1];
+#pragma unroll
+            for (int i = 0; i < AD; ++i) ar[i] = W43_AFRAG(ab_cur, i);
+#pragma unroll
+            for (int ls = 0; ls < NS; ++ls) {
+                half8 (&bc)[NCT] = bq[W43_SET(ls)];
+                if (ls + 1 < NS) MICA_BLOAD43(W43_SET(ls + 1), wcur, ls + 1);
+                else MICA_BLOAD43(W43_SET(0), wnxt, 0);
+                // in flight and NEWER than this step's fragments: the four loads just issued plus the previous step's slab DMA
+                const int newer = NCT + (ls >= 1 ? W43_NDMA(ls - 1) : 0);
+                if (newer == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
+                else asm volatile("s_waitcnt vmcnt(5)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < W43_NDMA(ls); ++q) MICA_SLAB_DMA43(nsrc, nxt_off, ls + q, org);
+                const char* ab_nxt = ab_cur;
+                if (ls + 1 < NS) ab_nxt = W43_ABASE(ls + 1);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const int fi = ls * NF + f;                 // fragment index within the chunk; lives in ar[fi % (AD + 1)]
+                    if (f + AD < NF) ar[(fi + AD) % (AD + 1)] = W43_AFRAG(ab_cur, f + AD);
+                    else if (ls + 1 < NS) ar[(fi + AD) % (AD + 1)] = W43_AFRAG(ab_nxt, f + AD - NF);
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(ar[fi % (AD + 1)]), "v"(bc[c]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ab_cur = ab_nxt;
+            }
+#undef W43_ABASE
+#undef W43_AFRAG
+            // the slab DMAs of this chunk are older than the four weight loads still wanted in flight
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __syncthreads();
+            par ^= 1;
+            wcur = wnxt;
+        }
+        // the next item's first weight fragments were requested a step ago: retire them here (the compiler cannot see them in flight)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]));
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU/LDS readers
+
+        // ---- output transform through the idle slab buffer: four passes of 32 columns; T = [z 4][p 6][row 16 = y*4+quad][32 + 4] floats ----
+        {
+            constexpr int CP = 32, RS = CP + 4, REG = 16 * RS;
+            static_assert(4 * 6 * REG * 4 <= G::CH_BYTES, "epilogue fits one slab buffer");
+            float* xs = reinterpret_cast<float*>(smem + (par ^ 1) * G::CH_BYTES);
+            const int ib = cur.b, inb = cur.nb, itile = cur.tile;
+            const int tx = itile % ntx, ty = (itile / ntx) % nty, tz = itile / (ntx * nty);
+            const int nnitem = nitem + per_xcd;
+            const Item nn = decode(nnitem < it_end ? nnitem : (has_next ? nitem : item));
+            const int fz = wave & 3, fch = (wave >> 2) & 1;          // finishing role of waves 0..7: z plane, 16-column half
+            const int frow = lane >> 2, fcg = lane & 3;
+            const int P = (items_per_b / nnb) * 4;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int c0 = (pass >> 1) * 2;                      // first column tile of the pass
+                const int wq = pass & 1;                             // the channel half (wave group) that writes T
+                if (wn == wq) {
+                    // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg  ->  row = y*4 + quad: y = lane >> 4, quad = reg
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        float* dst = xs + (f * 6 + wp) * REG;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) dst[(lg * 4 + i) * RS + c * 16 + lr] = acc[f][c0 + c][i];
+                    }
+                }
+                __syncthreads();
+                if (wave < 8) {
+                    const float* src = xs + (fz * 6) * REG + frow * RS + fch * 16 + fcg * 4;
+                    const int n0 = inb * BN + wq * 64 + (pass >> 1) * 32 + fch * 16 + fcg * 4;
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (bias) bv = *reinterpret_cast<const float4*>(bias + n0);
+                    const float4 m0 = *reinterpret_cast<const float4*>(src + 0 * REG);
+                    const float4 m1 = *reinterpret_cast<const float4*>(src + 1 * REG);
+                    const float4 m2 = *reinterpret_cast<const float4*>(src + 2 * REG);
+                    const float4 m3 = *reinterpret_cast<const float4*>(src + 3 * REG);
+                    const float4 m4 = *reinterpret_cast<const float4*>(src + 4 * REG);
+                    const float4 m5 = *reinterpret_cast<const float4*>(src + 5 * REG);
+                    const float a0[4] = {m0.x, m0.y, m0.z, m0.w}, a1[4] = {m1.x, m1.y, m1.z, m1.w}, a2[4] = {m2.x, m2.y, m2.z, m2.w};
+                    const float a3[4] = {m3.x, m3.y, m3.z, m3.w}, a4[4] = {m4.x, m4.y, m4.z, m4.w}, a5[4] = {m5.x, m5.y, m5.z, m5.w};
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                    float yv[4][4];                                  // [x within the quad][channel]
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float s12 = a1[c] + a2[c], d12 = a1[c] - a2[c], s34 = a3[c] + a4[c], d34 = a3[c] - a4[c];
+                        yv[0][c] = (a0[c] + s12 + s34) * out_scale + bb[c];
+                        yv[1][c] = (d12 + 2.f * d34) * out_scale + bb[c];
+                        yv[2][c] = (s12 + 4.f * s34) * out_scale + bb[c];
+                        yv[3][c] = (d12 + 8.f * d34 + a5[c]) * out_scale + bb[c];
+                    }
+                    const int gx = (tx * 4 + (frow & 3)) * 4, gy = ty * 4 + (frow >> 2), gz = tz * 4 + fz;
+                    // statistics: sums of (v - shift), (v - shift)^2 with one shift per channel for the whole wave (the tile's first voxel)
+                    float sk[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sk[c] = __shfl(yv[0][c], fcg);      // lane fcg holds row 0 of this channel group
+                    const bool inr = gy < d.H && gz < d.D;
+                    float sn = 0.f, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool in = inr && gx + j < d.W;
+                        if (in) {
+                            float* o = out + ((int64_t)ib * V + (int64_t)(gz * d.H + gy) * d.W + gx + j) * cout + n0;
+                            *reinterpret_cast<float4*>(o) = make_float4(yv[j][0], yv[j][1], yv[j][2], yv[j][3]);
+                        }
+                        const float wv = in ? 1.f : 0.f;
+                        sn += wv;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float t = (yv[j][c] - sk[c]) * wv;
+                            s1[c] += t;
+                            s2[c] = fmaf(t, t, s2[c]);
+                        }
+                    }
+                    if (stats_ws) {
+                        // lanes of one 4-channel group sit 4 apart: DPP rotations inside a row of 16 lanes, then two cross-row exchanges
+#define W43_ROR_ADD(x, n) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (n), 0xf, 0xf, false))
+                        W43_ROR_ADD(sn, 4);
+                        W43_ROR_ADD(sn, 8);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { W43_ROR_ADD(s1[c], 4); W43_ROR_ADD(s2[c], 4); W43_ROR_ADD(s1[c], 8); W43_ROR_ADD(s2[c], 8); }
+#undef W43_ROR_ADD
+#pragma unroll
+                        for (int off = 16; off < 64; off <<= 1) {
+                            sn += __shfl_xor(sn, off);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                s1[c] += __shfl_xor(s1[c], off);
+                                s2[c] += __shfl_xor(s2[c], off);
+                            }
+                        }
+                        if (frow == 0) {
+                            float* wsp = stats_ws + (((int64_t)ib * P + itile * 4 + fz) * cout + n0) * 3;
+                            const float inv = sn > 0.f ? 1.f / sn : 0.f;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                wsp[c * 3] = sn;
+                                wsp[c * 3 + 1] = sn > 0.f ? sk[c] + s1[c] * inv : 0.f;
+                                wsp[c * 3 + 2] = sn > 0.f ? fmaxf(s2[c] - s1[c] * s1[c] * inv, 0.f) : 0.f;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (!has_next) break;
+            item = nitem;
+            nitem = nnitem;
+            cur = nxt;
+            nxt = nn;
+        }
+    }
+#undef MICA_BLOAD43
+#undef MICA_SLAB_DMA43
+    // nothing may still be in flight towards this workgroup's registers or LDS when it ends
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]));
+#undef W43_SET
+#undef W43_NDMA
+#undef W43_TAP
+#undef W43_AOFF
+#undef W43_ADELTA
+#undef W43_WOFF
+#undef W43_WDELTA
+}
+
+bool conv_wino43_eligible(int cout) { return cout % 128 == 0; }
+
+// Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null): f32 [B][P][cout][3].
+int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out,
+                       int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
+    if (!conv_wino43_eligible(cout)) { fprintf(stderr, "conv_wino43: cout must be a multiple of 128\n"); abort(); }
+    int total = 0;
+    for (int i = 0; i < s.n; ++i) total += s.chunks[i];
+    const int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / 128;
+    const size_t lds = 2 * Geo43::CH_BYTES;
+    static unsigned long long seen = 0;
+    static int cus_of[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev > 63) dev = 0;
+    if (!(seen >> dev & 1ull)) {
+        seen |= 1ull << dev;
+        (void)hipFuncSetAttribute((const void*)conv_wino43_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipDeviceProp_t prop;
+        int c = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+        if (c < 8) c = 256;
+        cus_of[dev] = c & ~7;
+    }
+    const int cus = cus_of[dev];
+    const int items_per_b = ntx * nty * ntz * nnb, total_items = items_per_b * B;
+    const int nwg = total_items >= cus ? cus : ((total_items + 7) / 8) * 8;
+    hipLaunchKernelGGL(conv_wino43_kernel, dim3(nwg), dim3(768), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout, total, ntx,
+                       nty, nnb, items_per_b, total_items, stats_ws);
+    return ntx * nty * ntz * 4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights for conv_wino43: [B][nb = Cout/128][chunk][pair-step 5][p 6][unit 8][128][8] halves; unit u: 0,1 = hi of tap t (k-half
+// 0,1), 2,3 = hi of tap t' = t+1, 4,5 = lo of tap t, 6,7 = lo of tap t'; pair-step 4 is tap 8 alone (units 2,3,6,7 zero).
+// The weight transform u_p = sum_k G[p][k] g_k is done in f64 and rounded once to f32 before the power-of-two scaling.
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weights_wino43_kernel(const float* __restrict__ w, int cout, int cin, Segs43 sg, int total_chunks,
+                                           const float* __restrict__ cin_scale, float mul, _Float16* __restrict__ wpk, int64_t per_b) {
+    constexpr int bn = 128;
+    const int b = blockIdx.y;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [nb][chunk][ps 5][p 6][unit 8][n in block]
+    int64_t total = (int64_t)total_chunks * 5 * 6 * 8 * cout;
+    if (e >= total) return;
+    const int nl = e % bn;
+    const int u = (e / bn) & 7;
+    const int pp = (e / (bn * 8)) % 6;
+    const int ps = (e / (bn * 48)) % 5;
+    const int gch = (e / (bn * 240)) % total_chunks;
+    const int n = (int)(e / ((int64_t)bn * 240 * total_chunks)) * bn + nl;
+    const int kind = u >> 2, second = (u >> 1) & 1, kh = u & 1;
+    const int tap = 2 * ps + second;
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int kp = gch * 16 + kh * 8 + j;
+        int ci = -1, accp = 0, accc = 0;
+        for (int si = 0; si < sg.n; ++si) {
+            if (kp >= accp && kp < accp + sg.cp[si]) {
+                int local = kp - accp;
+                if (local < sg.c[si]) ci = accc + local;
+            }
+            accp += sg.cp[si];
+            accc += sg.c[si];
+        }
+        float v = 0.f;
+        if (ci >= 0 && tap < 9) {
+            const float* g = w + ((int64_t)n * cin + ci) * 27 + tap * 3;
+            const double g0 = g[0], g1 = g[1], g2 = g[2];
+            double uu;
+            switch (pp) {
+                case 0: uu = g0 / 4.0; break;
+                case 1: uu = -(g0 + g1 + g2) / 6.0; break;
+                case 2: uu = -(g0 - g1 + g2) / 6.0; break;
+                case 3: uu = g0 / 24.0 + g1 / 12.0 + g2 / 6.0; break;
+                case 4: uu = g0 / 24.0 - g1 / 12.0 + g2 / 6.0; break;
+                default: uu = g2; break;
+            }
+            v = (float)uu * mul;
+            if (cin_scale) v *= cin_scale[(int64_t)b * cin + ci];
+        }
+        _Float16 hi = (_Float16)v;
+        _Float16 lo = (_Float16)(v - (float)hi);
+        o[j] = kind ? lo : hi;
+    }
+    *reinterpret_cast<half8*>(wpk + (int64_t)b * per_b + e * 8) = o;
+}
+
+int64_t packed_weight_halves_wino43(int cout, int total_chunks) { return (int64_t)total_chunks * 5 * 48 * cout * 8; }
+
+void launch_pack_weights_wino43(const float* w, int cout, int cin, const int* h_seg_c, const int* h_seg_cp, int nseg,
+                                const float* cin_scale, int B, float cout_scale, float wscale, _Float16* wpk, hipStream_t st) {
+    Segs43 sg;
+    sg.n = nseg;
+    int total_chunks = 0;
+    for (int i = 0; i < nseg; ++i) {
+        sg.c[i] = h_seg_c[i];
+        sg.cp[i] = h_seg_cp[i];
+        total_chunks += h_seg_cp[i] / 16;
+    }
+    const int64_t total = (int64_t)total_chunks * 5 * 48 * cout;
+    dim3 grid((unsigned)((total + 255) / 256), B);
+    hipLaunchKernelGGL(pack_weights_wino43_kernel, grid, dim3(256), 0, st, w, cout, cin, sg, total_chunks, cin_scale, cout_scale * wscale,
+                       wpk, packed_weight_halves_wino43(cout, total_chunks));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Operand producers: y = relu?((x - mean) * rstd) of a raw f32 NDHWC tensor, written as the F(4,3) input transform of every
+// output quad in wino43 layout.  Thread = (8-channel group, quad).  enc.ascale is the scale of the OPERAND (the callers pass a
+// quarter of the context's activation scale, see the header).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino43_input_transform(const float (&dv)[6][8], float (&t)[6][8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float d0 = dv[0][j], d1 = dv[1][j], d2 = dv[2][j], d3 = dv[3][j], d4 = dv[4][j], d5 = dv[5][j];
+        t[0][j] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+        const float e = fmaf(-4.f, d2, d4), o = fmaf(-4.f, d1, d3);      // t1 = e + o ; t2 = e - o
+        t[1][j] = e + o;
+        t[2][j] = e - o;
+        const float e2 = d4 - d2, o2 = 2.f * (d3 - d1);                   // t3 = e2 + o2 ; t4 = e2 - o2
+        t[3][j] = e2 + o2;
+        t[4][j] = e2 - o2;
+        t[5][j] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_wino43_kernel(const float* __restrict__ x, Dims d, int C, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, int relu, SplitView wino, SplitEnc enc) {
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int Cs = C < 64 ? C : 64;                 // channel slab per block: a wave's stores form >= 512-B runs per chunk plane
+    const int G = Cs >> 3, SUB = 256 / G;
+    const int tid = threadIdx.x, g = blockIdx.z * (Cs >> 3) + tid % G, sub = tid / G;
+    const int Wq = (d.W + 3) >> 2;
+    const int V = d.D * d.H * d.W, Vq = d.D * d.H * Wq;
+    const int per = (Vq + nblk - 1) / nblk;
+    const int p0 = blk * per, p1 = min(Vq, p0 + per);
+    float m[8], r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t ci = (int64_t)b * C + g * 8 + j;
+        m[j] = mean ? mean[ci] : 0.f;
+        r[j] = rstd ? rstd[ci] : 1.f;
+    }
+    int bad = 0;
+    const float* xb = x + (int64_t)b * V * C + g * 8;
+    _Float16* wb = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + (g >> 1)) * (int64_t)Vq) * 192;
+    const int kh = g & 1;
+    for (int ph = p0 + sub; ph < p1; ph += SUB) {
+        const int row = ph / Wq, i = ph - row * Wq;
+        const int xo = 4 * i;
+        float dv[6][8];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int xx = xo - 1 + k;
+            const bool ok = (unsigned)xx < (unsigned)d.W;
+            const int xc = ok ? xx : xo;
+            const float4 a = *reinterpret_cast<const float4*>(xb + ((int64_t)row * d.W + xc) * C);
+            const float4 c = *reinterpret_cast<const float4*>(xb + ((int64_t)row * d.W + xc) * C + 4);
+            const float y[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = (y[j] - m[j]) * r[j];
+                if (relu) t = fmaxf(t, 0.f);
+                dv[k][j] = ok ? t : 0.f;
+            }
+        }
+        float t[6][8];
+        wino43_input_transform(dv, t);
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) {
+            half8 hi, lo;
+            mica_split8(t[pp], hi, lo, bad, enc.ascale);
+            *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + kh) * Vq + ph) * 8) = hi;
+            *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 2 + kh) * Vq + ph) * 8) = lo;
+        }
+    }
+    if (bad) atomicOr(enc.err, bad);
+}
+
+void launch_prep_wino43(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, int relu, SplitView wino,
+                        SplitEnc enc, hipStream_t st) {
+    const int Cs = C < 64 ? C : 64, G = Cs / 8, SUB = 256 / G;
+    const int Vq = d.D * d.H * ((d.W + 3) / 4);
+    int nblk = (Vq + SUB * 2 - 1) / (SUB * 2);
+    if (nblk > 4096) nblk = 4096;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL(prep_wino43_kernel, dim3(nblk, B, C / Cs), dim3(256), 0, st, x, d, C, mean, rstd, relu, wino, enc);
+}
+
+// NCDHW f32 [B][C][V] -> wino43 layout (single-op entry point)
+__global__ __launch_bounds__(256) void prep_ncdhw_wino43_kernel(const float* __restrict__ x, Dims d, int C, SplitView wino, SplitEnc enc) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int Wq = (d.W + 3) >> 2;
+    const int V = d.D * d.H * d.W, Vq = d.D * d.H * Wq;
+    const int ph = blockIdx.x * 256 + threadIdx.x;
+    if (ph >= Vq) return;
+    const int row = ph / Wq, i = ph - row * Wq, xo = 4 * i;
+    int bad = 0;
+    _Float16* wb = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + ch) * (int64_t)Vq) * 192;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        float dv[6][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = ch * 16 + kh * 8 + j;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int xx = xo - 1 + k;
+                dv[k][j] = (c < C && (unsigned)xx < (unsigned)d.W) ? x[((int64_t)b * C + c) * V + (int64_t)row * d.W + xx] : 0.f;
+            }
+        }
+        float t[6][8];
+        wino43_input_transform(dv, t);
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) {
+            half8 hi, lo;
+            mica_split8(t[pp], hi, lo, bad, enc.ascale);
+            *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + kh) * Vq + ph) * 8) = hi;
+            *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 2 + kh) * Vq + ph) * 8) = lo;
+        }
+    }
+    if (bad) atomicOr(enc.err, bad);
+}
+
+void launch_prep_ncdhw_wino43(const float* x, int B, Dims d, int C, SplitView wino, SplitEnc enc, hipStream_t st) {
+    const int Vq = d.D * d.H * ((d.W + 3) / 4);
+    dim3 grid((Vq + 255) / 256, (C + 15) / 16, B);
+    hipLaunchKernelGGL(prep_ncdhw_wino43_kernel, grid, dim3(256), 0, st, x, d, C, wino, enc);
+}
+
+}  // namespace mica

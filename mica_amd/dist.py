@@ -43,7 +43,8 @@ class RecordExchange:
     every rank.  With the gloo backend and device tensors (rehearsing N > 1 on one GPU) the records are staged through
     the host, synchronously."""
 
-    def __init__(self, batch: int, rec_shape, device, stitch, dtype=torch.float32, group=None, stitch_rank: int | None = 0):
+    def __init__(self, batch: int, rec_shape, device, stitch, dtype=torch.float32, group=None, stitch_rank: int | None = 0,
+                 force_collective: bool = False):
         self.group = group
         on = dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
@@ -51,16 +52,21 @@ class RecordExchange:
         self.batch, self.stitch, self.stitch_rank = batch, stitch, stitch_rank
         self.device = torch.device(device)
         self.backend = dist.get_backend(group) if on else None
+        # force_collective: take the collective path even in a group of ONE rank - the way to execute the RCCL branch
+        # (device tensors, async_op, work.wait() ordering, slot reuse) on a box with a single GPU
+        self.collective = self.world > 1 or (force_collective and on)
         self.send = [torch.zeros((batch, *rec_shape), dtype=dtype, device=device) for _ in range(2)]
         self.recv = None
-        if self.world > 1:
+        if self.collective:
             # one flat receive buffer per slot: [world * batch, ...]; rank rr's records are rows rr*batch ...
             self.recv = [torch.empty((self.world * batch, *rec_shape), dtype=dtype, device=device) for _ in range(2)]
         self.pending = None
+        self.collectives = 0          # all-gathers issued (tests assert the collective path really ran)
 
     def _gather(self, slot):
-        if self.world == 1:
+        if not self.collective:
             return None
+        self.collectives += 1
         if self.backend == "gloo" and self.device.type == "cuda":      # rehearsal of N > 1 on a GPU without RCCL: through the host
             host = torch.empty(self.recv[slot].shape, dtype=self.recv[slot].dtype)
             dist.all_gather_into_tensor(host, self.send[slot].cpu(), group=self.group)
@@ -77,7 +83,7 @@ class RecordExchange:
         if self.stitch_rank is None or self.rank == self.stitch_rank:
             for rr, (first, count) in enumerate(layout):
                 if count:
-                    src = self.recv[slot][rr * self.batch:] if self.world > 1 else self.send[slot]
+                    src = self.recv[slot][rr * self.batch:] if self.collective else self.send[slot]
                     self.stitch(src[:count], first)
 
     def post(self, r: int, rec, layout):
@@ -95,7 +101,7 @@ class RecordExchange:
 
 
 def sharded_records(run_batch, stitch, T: int, batch: int, rec_shape, device, dtype=torch.float32, group=None,
-                    stitch_rank: int | None = 0):
+                    stitch_rank: int | None = 0, force_collective: bool = False, stats: dict | None = None):
     """run_batch(first, count) -> tensor [count, *rec_shape] on `device`;
     stitch(records [count, *rec_shape], first) is called on `stitch_rank` (None = every rank) for every
     batch of every rank, in global tile order within a round."""
@@ -106,7 +112,8 @@ def sharded_records(run_batch, stitch, T: int, batch: int, rec_shape, device, dt
         seen[first] = seen.get(first, 0) + int(rec.shape[0])
         stitch(rec, first)
 
-    ex = RecordExchange(batch, rec_shape, device, counted, dtype=dtype, group=group, stitch_rank=stitch_rank)
+    ex = RecordExchange(batch, rec_shape, device, counted, dtype=dtype, group=group, stitch_rank=stitch_rank,
+                        force_collective=force_collective)
     mine, rounds = rank_batches(T, batch, ex.rank, ex.world)
     for r, first, count in mine:
         layout = [plan[r * ex.world + rr] if r * ex.world + rr < len(plan) else (0, 0) for rr in range(ex.world)]
@@ -117,4 +124,6 @@ def sharded_records(run_batch, stitch, T: int, batch: int, rec_shape, device, dt
         # the volumes or overwrite a region silently)
         if seen != dict(plan):
             raise RuntimeError(f"sharded_records: stitched batches {sorted(seen.items())} != plan {plan}")
+    if stats is not None:
+        stats.update(collectives=ex.collectives, backend=ex.backend, world=ex.world, rounds=rounds)
     return rounds

@@ -39,6 +39,8 @@ class Engine:
             raise MicaHipError(f"mica_create failed ({r}): {self.lib.mica_last_error(None).decode()}")
         self._h = h
         self.weights_loaded = False
+        self.last_forward_scale = 16.0     # lowest activation scale any chunk of the last forward_* call needed
+        self.forward_retries = 0           # chunks of the last forward_* call that had to repeat a tile at a lower scale
 
     # -- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -79,10 +81,17 @@ class Engine:
     # -- forward ----------------------------------------------------------------------------------
     LOW_SCALE_WARN = 0.25      # below this the split encoding loses bits: the call still succeeds, loudly
 
+    def _begin_forward(self):
+        """A public forward_* call may be cut into several C calls (T > max_batch): the scale reported is the lowest of them."""
+        self.last_forward_scale = float(self.lib.mica_get_activation_scale(self._h))
+        self.forward_retries = 0
+
     def _check_forward(self, r, what):
         self._check(r, what)
         sc = float(self.lib.mica_get_last_forward_scale(self._h))
-        self.last_forward_scale = sc
+        if sc < float(self.lib.mica_get_activation_scale(self._h)):
+            self.forward_retries += 1
+        self.last_forward_scale = min(self.last_forward_scale, sc)
         if sc < self.LOW_SCALE_WARN:
             import warnings
             warnings.warn(f"{what}: activations of a tile exceeded {60000 / self.LOW_SCALE_WARN:.0f}; it was computed at activation "
@@ -108,6 +117,7 @@ class Engine:
         bb = torch.empty((B, 4, S, S, S), dtype=torch.float32, device=self.device)
         ca = torch.empty_like(bb)
         aa = torch.empty((B, 21, S, S, S), dtype=torch.float32, device=self.device)
+        self._begin_forward()
         for b0 in range(0, B, self.max_batch):
             b1 = min(B, b0 + self.max_batch)
             self._check_forward(self.lib.mica_forward_logits(
@@ -130,6 +140,7 @@ class Engine:
                    torch.empty((T, 20, S, S, S), dtype=torch.float32, device=self.device),
                    torch.empty((T, S, S, S), dtype=torch.float32, device=self.device))
         bbp, cap, aap, pred = out
+        self._begin_forward()
         for b0 in range(0, T, self.max_batch):
             b1 = min(T, b0 + self.max_batch)
             self._check_forward(self.lib.mica_forward_tiles(
@@ -149,6 +160,7 @@ class Engine:
         self._check_batch_mode(T, af_tiles, af_mode)
         if rec.dtype != torch.float32 or not rec.is_cuda or not rec.is_contiguous() or tuple(rec.shape) != (T, 23, S, S, S):
             raise MicaHipError(f"rec must be a contiguous float32 CUDA(HIP) tensor [{T},23,{S},{S},{S}]")
+        self._begin_forward()
         for b0 in range(0, T, self.max_batch):
             b1 = min(T, b0 + self.max_batch)
             self._check_forward(self.lib.mica_forward_records(

@@ -139,9 +139,12 @@ class VolumePredictor:
             results[len(maps) - 1] = collect(pending)
         return results
 
-    def predict_volume_sharded(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None, group=None):
+    def predict_volume_sharded(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None, group=None,
+                               force_collective: bool = False, stats: dict | None = None):
         """Multi-GPU form: every rank holds the (normalised) volume, runs its share of the tile batches and
-        the cropped records are all-gathered (RCCL); rank 0 returns the dict, the other ranks return None."""
+        the cropped records are all-gathered (RCCL); rank 0 returns the dict, the other ranks return None.
+        force_collective: run the all-gather even in a process group of one rank (executes the RCCL branch on one GPU);
+        stats (optional dict) receives the number of collectives issued, the backend and the world size."""
         import torch.distributed as dist
         from .dist import sharded_records
         e = self.e
@@ -157,7 +160,8 @@ class VolumePredictor:
         def stitch(rec, first):
             e.stitch_tiles(rec.contiguous(), out, g, 0, first)      # cropped records: window = grid, no halo
 
-        sharded_records(run, stitch, T, self.batch, (23, g, g, g), e.device, group=group, stitch_rank=0)
+        sharded_records(run, stitch, T, self.batch, (23, g, g, g), e.device, group=group, stitch_rank=0,
+                        force_collective=force_collective, stats=stats)
         if rank != 0:
             return None
         return {"backbone_probability": out[0], "carbon_alpha_probability": out[1],

@@ -142,6 +142,7 @@ class CryoEMPredictor:
             copy_stream = torch.cuda.Stream(device=e.device)
             main_stream = torch.cuda.current_stream(e.device)
             pins = {}
+            uploaded = {}        # buffer parity -> event of the last upload that read the pinned pair
 
             def stage(r, futs):
                 """host side of run r, on a helper thread: wait for its tile files, assemble the batch in pinned memory (two
@@ -153,6 +154,8 @@ class CryoEMPredictor:
                     pins[k] = (torch.empty((B, 1, S, S, S), dtype=torch.float32).pin_memory(),
                                torch.empty((B, 24, S, S, S), dtype=torch.float32).pin_memory())
                 px, pa = pins[k]
+                if k in uploaded:
+                    uploaded[k].synchronize()      # host-side: the non-blocking upload of run r - 2 has finished reading this pair
                 any_af = False
                 for q, it in enumerate(items):
                     px[q].copy_(torch.from_numpy(it[0]))
@@ -163,6 +166,7 @@ class CryoEMPredictor:
                     af = pa[:n].to(e.device, non_blocking=True) if any_af else None
                     ev = torch.cuda.Event()
                     ev.record(copy_stream)
+                uploaded[k] = ev
                 return x, af, ev
 
             with ThreadPoolExecutor(max_workers=self.loader_threads) as pool, ThreadPoolExecutor(max_workers=1) as stager:
@@ -172,8 +176,8 @@ class CryoEMPredictor:
                     if r + ahead < len(runs):
                         loads.append([pool.submit(dataset.__getitem__, t) for t in runs[r + ahead]])
                     if r + 1 < len(runs):
-                        # the pinned buffers of parity (r + 1) & 1 were last read by the upload of run r - 1, which the forward of
-                        # run r - 1 already waited for
+                        # the pinned buffers of parity (r + 1) & 1 were last read by the upload of run r - 1: stage() waits for that
+                        # upload's event on the host before it rewrites them (it does not rely on the forward being synchronous)
                         staged.append(stager.submit(stage, r + 1, loads.pop(0)))
                     x, af, ev = staged.pop(0).result()
                     main_stream.wait_event(ev)

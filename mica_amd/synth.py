@@ -29,3 +29,61 @@ def synth_af(shape, seed: int, p: float = 1e-3) -> np.ndarray:
 def synth_map_fast(n: int, seed: int) -> np.ndarray:
     """Large benchmark maps: default_rng(seed).random((n,n,n), float32)."""
     return np.random.default_rng(seed).random((n, n, n), dtype=np.float32)
+
+
+def synth_blob_map(shape, seed: int, n_blobs: int, rmin: float = 3.0, rmax: float = 6.0):
+    """A map shaped like the normaliser's output (reference utils/preprocessing.py:122-133: zero below the median, clipped at
+    the 99.9th percentile and scaled to [0, 1]): exact zeros over most of the volume and `n_blobs` compact bumps
+    (1 - r^2/R^2)^2 whose centre voxels reach 1.0.  Only + - * / on float64 (bit-reproducible on every host).
+    Returns (map float32 `shape`, centres int64 [n_blobs, 3])."""
+    D, H, W = shape
+    u = hash_uniform("blobs", 4 * n_blobs, seed).reshape(n_blobs, 4)
+    dims = np.array([D, H, W], dtype=np.float64)
+    cen = np.floor((u[:, :3] + 1.0) * 0.5 * dims).astype(np.int64)
+    rad = rmin + (u[:, 3] + 1.0) * 0.5 * (rmax - rmin)
+    z, y, x = np.meshgrid(np.arange(D, dtype=np.float64), np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    vol = np.zeros(shape, dtype=np.float64)
+    for (cz, cy, cx), R in zip(cen, rad):
+        r2 = (z - cz) ** 2 + (y - cy) ** 2 + (x - cx) ** 2
+        q = 1.0 - r2 / (R * R)
+        vol = np.maximum(vol, np.where(q > 0.0, q * q, 0.0))
+    return vol.astype(np.float32), cen
+
+
+def synth_af_clustered(shape, seed: int, centres) -> np.ndarray:
+    """AF3 encodings clustered the way atom rasters are (reference utils/preprocessing.py:283-298): around every centre a
+    'residue' - the four backbone channels CA, N, C, O at neighbouring voxels and one amino-acid channel (4..23) set at those
+    same voxels - instead of the independent Bernoulli voxels of :func:`synth_af`."""
+    D, H, W = shape
+    af = np.zeros((24, D, H, W), dtype=np.float32)
+    offs = ((0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 0, 0))
+    u = hash_uniform("af3c", len(centres), seed)
+    for (cz, cy, cx), t in zip(centres, u):
+        aa = 4 + int((t + 1.0) * 0.5 * 20) % 20
+        for ch, (dz, dy, dx) in enumerate(offs):
+            p = (min(max(int(cz) + dz, 0), D - 1), min(max(int(cy) + dy, 0), H - 1), min(max(int(cx) + dx, 0), W - 1))
+            af[(ch,) + p] = 1.0
+            af[(aa,) + p] = 1.0
+    return af
+
+
+def stress_case(kind: str, S: int):
+    """Inputs of the round-4 stress goldens (oracle/gen_golden_r4.py, tests/golden/r4_*): -> (weights dict, map float32
+    [1,1,S,S,S], AF3 encodings float32 [1,24,S,S,S]).  kind 'heavy' = heavy-tailed weights on uniform density with Bernoulli
+    encodings; 'blob' = the default weights on a normaliser-shaped map (> 80 % zeros, blobs reaching 1.0) with encodings
+    clustered as residues at the blob centres."""
+    from .weights import synth_state_dict, synth_state_dict_heavy
+    if kind == "heavy":
+        w = synth_state_dict_heavy(5, 6.0)
+        seed = 12 if S == 16 else 33
+        x = synth_density((1, 1, S, S, S), seed)
+        af = synth_af((S, S, S), seed, 0.01 if S == 16 else 1e-3)[None]
+    elif kind == "blob":
+        w = synth_state_dict(2022, 6.0)
+        seed = 71 if S == 16 else 72
+        m, cen = synth_blob_map((S, S, S), seed, 6 if S == 16 else 60, 3.0 if S == 16 else 4.0, 5.0 if S == 16 else 8.0)
+        x = m[None, None]
+        af = synth_af_clustered((S, S, S), seed, cen)[None]
+    else:
+        raise ValueError(kind)
+    return w, np.ascontiguousarray(x), np.ascontiguousarray(af)

@@ -139,3 +139,32 @@ def load_checkpoint_state_dict(path: str) -> "OrderedDict[str, np.ndarray]":
     if missing:
         raise KeyError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:3]}")
     return out
+
+
+def synth_state_dict_heavy(seed: int = 5, final_gain: float = 6.0, outlier: float = 30.0) -> "OrderedDict[str, np.ndarray]":
+    """Heavy-tailed variant of :func:`synth_state_dict` (round 4: what a trained network could stress that U(-b, b) does not):
+    every weight's magnitude is multiplied by a random power of two in 2^-4 .. 2^3 (a log-uniform spread of 128x; exact
+    arithmetic, so the generator stays bit-reproducible), and about 3 % of the output channels of every conv / linear layer
+    (at least one per layer with >= 16 outputs) are `outlier` times larger than the rest."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in param_shapes().items():
+        n = int(np.prod(shape))
+        u = hash_uniform(name, n, seed)
+        if name == "fpn.weights":
+            v = 0.5 * u
+        elif name.endswith(".bias"):
+            v = 0.1 * u
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            e = np.floor(4.0 * hash_uniform(name + "#exp", n, seed))          # -4 .. 3
+            v = math.sqrt(3.0 / fan_in) * 0.3 * u * np.exp2(e)
+            cout = shape[0]
+            if cout >= 16 and ".final." not in name:
+                pick = hash_uniform(name + "#out", cout, seed)
+                hot = pick < -0.94
+                hot[int(np.argmin(pick))] = True
+                v = (v.reshape(cout, -1) * np.where(hot, outlier, 1.0)[:, None]).reshape(-1)
+            if ".final." in name:
+                v = v * final_gain
+        out[name] = v.astype(np.float32).reshape(shape)
+    return out

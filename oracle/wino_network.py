@@ -21,6 +21,7 @@ Variants of the 3^3 convs:
     f43h@128   the same with the +-1/2 points
     f43@big    F(4,3) on encoder.2's conv3 (512->256) and transition (256->512) only - 51 % of the network's FLOPs
     f43h@big   the same with the +-1/2 points
+    f43@e2     F(4,3) on all four 3^3 convs of encoder.2 (68 % of the FLOPs)
 
 Criterion (tests/test_gpu_model.py): scaled error max |got - ref| / max(|ref|, rms(ref)) < 1e-4 against the reference module's
 float32 logits (tests/golden/model_S16_*.npz) AND against its float64 logits (truth64_S16_*.npz), the latter also <= 1.5x the
@@ -188,8 +189,12 @@ class Emulated:
         self.variant = variant
         self.log = []
 
-    def pick(self, cin, cout):
+    def pick(self, cin, cout, name=""):
         v = self.variant
+        if "@e2" in v:                                    # all four 3^3 convs of encoder.2 (conv1, conv2, conv3, transition)
+            return {"f43": F43, "f43h": F43H}[v.split("@")[0]] if name.startswith("encoder.2.") else F23
+        if "@e2c" in v:
+            pass
         if v == "direct":
             return None
         if "@128" in v:
@@ -206,7 +211,7 @@ class Emulated:
             wt, bs = mo._t(w, name + ".weight"), mo._t(w, name + ".bias")
             if self.variant != "f32" and groups == 1 and x.shape[0] == 1 and x.shape[2] > 1:
                 if tuple(wt.shape[2:]) == (3, 3, 3) and wt.shape[1] >= 16:
-                    return conv3_emulated(x, wt, bs, self.pick(wt.shape[1], wt.shape[0]))
+                    return conv3_emulated(x, wt, bs, self.pick(wt.shape[1], wt.shape[0], name))
                 if tuple(wt.shape[2:]) == (1, 1, 1) and wt.shape[0] >= 64:
                     return conv1_emulated(x, wt, bs)
             return orig(w, name, x, pad, groups)

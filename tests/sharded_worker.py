@@ -1,6 +1,8 @@
-"""One rank of the 2-rank rehearsal of BASELINE configs[2] on a single GPU (started by tests/test_gpu_configs.py as a
-fresh child process; gloo rendezvous on 127.0.0.1, every rank on cuda:0): runs VolumePredictor.predict_volume_sharded
-with the real engine; rank 0 writes the four volumes."""
+"""One rank of the rehearsals of BASELINE configs[2] on a single GPU (started by tests/test_gpu_configs.py as a fresh child
+process, rendezvous on 127.0.0.1, every rank on cuda:0): runs VolumePredictor.predict_volume_sharded with the real engine;
+rank 0 writes the four volumes.  MICA_TEST_BACKEND=gloo (default; two ranks, records staged through the host) or nccl
+(= RCCL; ONE rank with force_collective, which executes the production branch of RecordExchange: device tensors,
+all_gather_into_tensor(async_op=True), work.wait() ordering, double-buffered slots)."""
 import os
 import sys
 
@@ -21,7 +23,13 @@ def main():
     from mica_amd.synth import synth_af, synth_density
     from mica_amd.weights import synth_state_dict
 
-    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    backend = os.environ.get("MICA_TEST_BACKEND", "gloo")
+    force = backend == "nccl"
+    if backend == "nccl":       # the group comes first: nothing else has touched the GPU in this process
+        dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]),
+                                device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     eng = Engine(0, max_batch=batch, tile_size=64)
     eng.load_state_dict(synth_state_dict(2022))
     vol = torch.from_numpy(synth_density(shape, seed)).cuda()
@@ -30,7 +38,8 @@ def main():
         af[:, :zero_x] = 0                                 # windows that end before x = zero_x see no atoms
     else:
         af[:, :, :, : shape[2] // 2] = 0                   # some tiles see no atoms: per-tile gating on every rank
-    out = VolumePredictor(eng, grid, pad, batch).predict_volume_sharded(vol, af)
+    stats = {}
+    out = VolumePredictor(eng, grid, pad, batch).predict_volume_sharded(vol, af, force_collective=force, stats=stats)
     # coverage of the sharded stitch: all-one records through the same exchange fill a counter volume (no hole), and
     # sharded_records itself raises unless every batch arrived exactly once
     from mica_amd.dist import sharded_records
@@ -38,9 +47,10 @@ def main():
     cover = torch.zeros((1, *shape), device="cuda")
     ones = torch.ones((batch, 1, grid, grid, grid), device="cuda")
     sharded_records(lambda first, count: ones[:count], lambda rec, first: eng.stitch_tiles(rec.contiguous(), cover, grid, 0, first),
-                    T, batch, (1, grid, grid, grid), torch.device("cuda"), stitch_rank=0)
+                    T, batch, (1, grid, grid, grid), torch.device("cuda"), stitch_rank=0, force_collective=force)
     if dist.get_rank() == 0:
-        np.savez(out_path, coverage=cover[0].cpu().numpy(), **{k: v.cpu().numpy() for k, v in out.items()})
+        np.savez(out_path, coverage=cover[0].cpu().numpy(), collectives=stats["collectives"], backend=str(stats["backend"]),
+                 **{k: v.cpu().numpy() for k, v in out.items()})
     else:
         assert out is None
     dist.barrier()

@@ -368,3 +368,23 @@ def test_check_mode_detects_a_changed_fixture(tmp_path, golden_dir):
     assert len(log) >= 3, log
     _, log2 = compare_dirs(str(prod), golden_dir, exact=False, tol=1e-4)      # one ulp is inside the float tolerance
     assert not any("normaliser_ref_f32_40" in line for line in log2)
+
+
+@pytest.mark.parametrize("kind", ["heavy", "blob"])
+def test_model_oracle_matches_reference_on_stress_goldens(golden_dir, kind):
+    """Round-4 goldens (reference MICA on heavy-tailed weights / a normaliser-shaped map, oracle/gen_golden_r4.py): the oracle
+    reproduces the reference's float32 logits, and the generators of those inputs are what the fixture metadata says."""
+    from mica_amd.synth import stress_case
+    g = np.load(os.path.join(golden_dir, f"r4_{kind}_S16.npz"))
+    w, x, af = stress_case(kind, 16)
+    if kind == "blob":
+        assert (x == 0).mean() > 0.5 and x.max() == 1.0 and af.sum() > 0
+    else:
+        k = np.abs(w["encoder.1.dense_block.conv3.0.weight"]).reshape(128, -1).max(1)
+        assert np.sort(k)[-1] > 20 * np.median(k)                      # outlier output channels
+    torch.set_num_threads(8)
+    out = mo.mica_forward(w, torch.from_numpy(x), torch.from_numpy(af))
+    for got, key in zip(out, ("bb", "ca", "aa")):
+        ref = g[key]
+        scale = np.maximum(np.abs(ref), np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+        assert np.max(np.abs(got.numpy() - ref) / scale) < 1e-4

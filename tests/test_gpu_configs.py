@@ -217,6 +217,33 @@ def test_config2_two_ranks_on_one_gpu_equal_single_rank(tmp_path, eng):
     assert float(ref["backbone_probability"].max()) > 0.5
 
 
+def test_config2_rccl_branch_single_rank_equals_plain_pipeline(tmp_path, eng):
+    """The production branch of the record exchange - RCCL all_gather_into_tensor(async_op=True) on device tensors, work.wait()
+    ordering against the stitch kernels, double-buffered send / receive slots - executed on the hardware that exists: ONE rank in
+    an `nccl` process group with force_collective (a fresh child process that initialises the group before any other GPU call).
+    predict_volume_sharded under it equals predict_volume bit for bit, every batch went through a collective, and an all-ones
+    record set stitched through the same exchange covers the volume exactly once."""
+    from mica_amd.pipeline import VolumePredictor
+    shape, batch = (100, 70, 50), 2                        # 12 tiles -> 6 rounds on the one rank: both slots reused three times
+    out = str(tmp_path / "rccl1.npz")
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MICA_TEST_BACKEND="nccl")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), out, "x".join(map(str, shape)), str(batch)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+    got = np.load(out)
+    assert str(got["backend"]) == "nccl" and int(got["collectives"]) == 6
+    assert np.array_equal(got["coverage"], np.ones(shape, np.float32))
+    vol = torch.from_numpy(synth_density(shape, 91)).cuda()
+    af = torch.from_numpy(synth_af(shape, 91, 2e-3)).cuda()
+    af[:, :, :, : shape[2] // 2] = 0
+    ref = VolumePredictor(eng, 48, 8, batch).predict_volume(vol, af)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k].cpu().numpy()), k
+
+
 def test_config4_four_384_maps_streamed(eng):
     """BASELINE configs[4] at full size: four independent 384^3 maps (two with AF3 encodings) streamed back to back with
     double-buffered H2D/D2H.  Checked against the one-map-at-a-time pipeline: map 0 completely (bit for bit), the others
