@@ -50,6 +50,10 @@ SIGNATURES = {
     "mica_neighbour_matrix_np": (_I, [_P, _P, _L, _P, _L, _L, _L, _I, _P, _P, _P]),
     "mica_op_conv3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _I, _P, _P]),
     "mica_op_norm_conv1_conv3": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _FP, _FP, _I, _P, _P]),
+    "mica_op_conv3d_variant": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _I, _I, _P, _P]),
+    "mica_op_norm_conv1_conv3_variant": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _I, _FP, _FP, _I, _I, _P, _P]),
+    "mica_set_conv_variant": (_I, [_P, _I]),
+    "mica_get_conv_variant": (_I, [_P]),
     "mica_op_instnorm_relu": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mica_op_depthwise3": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _P, _P]),
     "mica_op_se_depthwise": (_I, [_P, _P, _I, _I, _I, _I, _I, _FP, _FP, _FP, _FP, _FP, _FP, _P, _P]),

@@ -25,10 +25,10 @@
 //
 // Kernel structure = conv_wino16_kernel<128> re-dimensioned (same MFMA shape v_mfma_f32_16x16x32_f16, same regrouping of the three
 // split products into X / X' / Y steps over tap pairs, same persistent item walk, slab LDS-DMA with counted vmcnt, asm weight
-// prefetch): workgroup = 12 waves = 6 positions x 2 channel halves; output tile 16(x) = 4 quads x 4(y) x 4(z); wave (p, wn) owns
-// Winograd position p for all 64 (quad, y, z) rows and 64 channels = 4 row fragments (one per z: 4 quads x 4 y) x 4 column tiles
-// = 64 accumulator VGPRs, three waves per SIMD.  LDS image per chunk: 4 planes (hi/lo x k-half) x [z 6][p 6][y 6][quad 4] 16-B
-// slots = 55,296 B, double buffered.  Per chunk and workgroup 2,688 MFMAs instead of 3,584 for the same 256 voxels x 128
+// prefetch): workgroup = 12 waves = 6 positions x 2 channel halves; output tile 32(x) = 8 quads x 2(y) x 4(z); wave (p, wn) owns
+// Winograd position p for all 64 (quad, y, z) rows and 64 channels = 4 row fragments (one per z: 8 quads x 2 y) x 4 column tiles
+// = 64 accumulator VGPRs, three waves per SIMD.  LDS image per chunk: 4 planes (hi/lo x k-half) x [z 6][p 6][y 4][quad 8] 16-B
+// slots = 73,728 B, double buffered.  Per chunk and workgroup 2,688 MFMAs instead of 3,584 for the same 256 voxels x 128
 // channels; a weight fragment feeds 4 MFMAs (8 in the F(2,3) kernel: the weight stream from L2 is 1.5x per output).
 #include "common.h"
 #include <cstdio>
@@ -39,23 +39,51 @@ namespace mica {
 struct Segs43 { int c[MAX_SRC]; int cp[MAX_SRC]; int n; };
 
 struct Geo43 {
-    static constexpr int SY = 6, SZ = 6, NP = 6, QX = 4;
-    static constexpr int PP = SY * QX;                 // 24 slots per (z, p)
-    static constexpr int PZ = NP * PP;                 // 144 slots per z plane
-    static constexpr int PLANE = SZ * PZ;              // 864 slots per (hi/lo, k-half) plane
-    static constexpr int NSLOT = 4 * PLANE;            // 3456
-    static constexpr int CH_BYTES = NSLOT * 16;        // 55,296
-    static constexpr int NDMA = NSLOT / 64;            // 54 one-KiB LDS-DMA instructions per chunk
+    // output tile 32(x) = 8 quads x 2(y) x 4(z): a slab row is 8 quads = 128 contiguous bytes per plane in HBM (with 4 quads per
+    // row - a 16 x 4 x 4 tile - every slab DMA touched half of each 128-byte line it named and the HBM slab stream cost 13 % of
+    // the kernel; tools/exp/abl43.sh)
+    static constexpr int TY = 2, TZ = 4;               // output rows / planes per tile
+    static constexpr int SY = TY + 2, SZ = TZ + 2, NP = 6, QX = 8;
+    static constexpr int PP = SY * QX;                 // 32 slots per (z, p)
+    static constexpr int PZ = NP * PP;                 // 192 slots per z plane = 3 DMA instructions
+    static constexpr int PLANE = SZ * PZ;              // 1152 slots per (hi/lo, k-half) plane
+    static constexpr int NSLOT = 4 * PLANE;            // 4608
+    static constexpr int CH_BYTES = NSLOT * 16;        // 73,728
+    static constexpr int NDMA = NSLOT / 64;            // 72 one-KiB LDS-DMA instructions per chunk
     static constexpr int NW = 12;                      // waves per workgroup
-    static constexpr int DPW = 5;                      // DMA slots per wave and chunk (12 x 5 = 60 >= 54; the last six are no-ops)
+    static constexpr int DPW = 6;                      // DMA instructions per wave and chunk
     static constexpr int BN = 128;
 };
-static_assert(Geo43::NSLOT % 64 == 0 && Geo43::NDMA <= Geo43::NW * Geo43::DPW, "slab DMA plan");
+static_assert(Geo43::NSLOT % 64 == 0 && Geo43::NDMA == Geo43::NW * Geo43::DPW && Geo43::PZ == 192 && Geo43::PP == 32 && Geo43::QX == 8 &&
+              Geo43::PLANE == 18 * 64, "slab DMA plan: the lane / scalar split of the source offsets in the kernel assumes this geometry");
 
 typedef float floatx4w __attribute__((ext_vector_type(4)));
+// development switches (timing experiments only, results are garbage; tools/exp/abl43.sh): -DMICA43_W_FIXED every weight fragment
+// load hits the same 4 KB per wave (L1 instead of the L2 stream); -DMICA43_SLAB_FIXED the slab DMAs wrap into the first 4 MB of
+// the operand (L2 instead of HBM); -DMICA43_NOEPI no output-transform passes
+#ifdef MICA43_ALLFIX
+#define MICA43_W_FIXED
+#define MICA43_SLAB_FIXED
+#define MICA43_NOEPI
+#endif
+#ifdef MICA43_W_FIXED
+#define MICA43_WBASE(b, off) (wwave)
+#else
+#define MICA43_WBASE(b, off) ((b) + (off))
+#endif
+#ifdef MICA43_SLAB_FIXED
+#define MICA43_SLABOFF(x) ((x) & 0x3FFFF0)
+#define MICA43_SLABBASE(b) (s.p[0])
+#else
+#define MICA43_SLABOFF(x) (x)
+#define MICA43_SLABBASE(b) (b)
+#endif
+#ifdef MICA43_NOEPI
+#define MICA43_EPI_PASSES 0
+#else
+#define MICA43_EPI_PASSES 4
+#endif
 
-__device__ __forceinline__ constexpr int w43_step_ps(int st) { return st < 12 ? st / 3 : 4; }
-__device__ __forceinline__ constexpr int w43_step_kind(int st) { return st < 12 ? st % 3 : (st - 12) * 2; }   // 0 Y, 1 X' (second tap), 2 X (first tap)
 
 __device__ __forceinline__ const _Float16* chunk_base_wino43(const ConvSrcs& s, int gch, int b, int Vq) {
     int si = 0, ch = gch;
@@ -70,7 +98,7 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                                                           Dims d, int cout, int total_chunks, int ntx, int nty, int nnb,
                                                           int items_per_b, int total_items, float* __restrict__ stats_ws) {
     using G = Geo43;
-    constexpr int BN = G::BN, NCT = 4, NS = 14, NF = 4;
+    constexpr int BN = G::BN, NCT = 4, NS = 10, NF = 4;      // NS: steps per chunk (4 x (a, bc) + x + y)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -86,7 +114,7 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     int item = xcd * range + lwg;
     if (item >= it_end) return;
 
-    // A operand: lane = (row r = lane & 15 -> quad r & 3, y r >> 2 ; k-group g = lane >> 4); a fragment is one z plane of the tile
+    // A operand: lane = (row r = lane & 15 -> quad r & 7, y r >> 3 ; k-group g = lane >> 4); a fragment is one z plane of the tile
     const int lr = lane & 15, lg = lane >> 4;
     const int himask = (lg >> 1) ? -1 : 0;
     const int a_common = ((lg & 1) * G::PLANE + wp * G::PP + lr) * 16;
@@ -99,51 +127,64 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     const int64_t nbstride = (int64_t)total_chunks * chstride;
     const char* wwave = reinterpret_cast<const char*>(wpk) + wp * 8 * ustride + wn * 64 * 16;
 
-    half8 bq[2][NCT];
-#define W43_TAP(st) (2 * w43_step_ps(st) + (w43_step_kind(st) == 1 ? 1 : 0))
-#define W43_AOFF(st) (((W43_TAP(st) / 3) * G::PZ + (W43_TAP(st) % 3) * G::QX) * 16)
-#define W43_ADELTA(st) (w43_step_kind(st) != 0 ? 2 * G::PLANE * 16 : (w43_step_ps(st) == 1 ? (G::PZ - 2 * G::QX) * 16 : G::QX * 16))
-#define W43_WOFF(st) (w43_step_ps(st) * psstride + (w43_step_kind(st) == 0 ? 4 : w43_step_kind(st) == 1 ? 2 : 0) * ustride)
-#define W43_WDELTA(st) (w43_step_kind(st) == 0 ? 2 * BN * 16 : 0)
-#define MICA_BLOAD43(set, wbase, ls)                                                                                    \
+    // Weight fragments and the step schedule.  The three split products of a tap pair (t, t') are grouped so that operands are
+    // shared between MFMAs:  with  Ahi = [a_hi(t) | a_hi(t')], Alo = [a_lo(t) | a_lo(t')]  (k-groups 0,1 = the two channel halves at
+    // tap t, 2,3 at tap t') and  H = [b_hi(t) ; b_hi(t')], L = [b_lo(t) ; b_lo(t')]:
+    //     step a  : Alo . H                    (16 MFMAs per wave)
+    //     step bc : Ahi . H  and  Ahi . L      (32 MFMAs: every A fragment feeds 8)
+    // and tap 8, which has no partner:  x: [a_hi(8) | a_lo(8)] . [b_hi(8) ; b_hi(8)],  y: the same A . [b_lo(8) ; 0].
+    // Per chunk that is 10 weight-fragment sets and 40 A-fragment reads for the same 224 MFMAs that the X / X' / Y grouping of
+    // conv_wino16_kernel feeds with 14 and 56: this kernel's weight fragments feed 4 MFMAs each (8 there), and with 14 sets per
+    // chunk their loads alone kept the vector L1 busy for as long as the MFMAs take (12 waves x 56 KiB per chunk at 64 B/clk).
+    // Three register sets hold the fragments: H of pair-step ps in set {0,1,0,1,2}[ps], L in {2,2,2,0,1}[ps] - after the five
+    // pair-steps of a chunk the assignment is back where it started, so every index is a compile-time constant; H is requested
+    // three steps (48 MFMAs) ahead, L one step.
+    half8 bq[3][NCT];
+#define W43_PS(st) ((st) < 8 ? (st) / 2 : 4)
+#define W43_KIND(st) ((st) < 8 ? (st) & 1 : (st) - 6)          /* 0 a, 1 bc, 2 x, 3 y */
+#define W43_HSET(ps) ((ps) == 4 ? 2 : (ps) & 1)
+#define W43_LSET(ps) ((ps) < 3 ? 2 : (ps) == 3 ? 0 : 1)
+#define W43_AOFF_TAP(tap) ((((tap) / 3) * G::PZ + ((tap) % 3) * G::QX) * 16)
+#define W43_PAIRDELTA(ps) ((ps) == 1 ? (G::PZ - 2 * G::QX) * 16 : G::QX * 16)
+#define W43_NDMA(st) ((st) >= 0 && (st) < G::DPW ? 1 : 0)
+    // one fragment set: four 16-cout column tiles, 256 B apart; `delta` (bytes, applied to k-groups 2,3) selects the second tap's units
+#define MICA_BLOAD43(set, base, off, delta)                                                                             \
     do {                                                                                                                \
-        const char* pb_ = (wbase) + W43_WOFF(ls);                                                                       \
-        const unsigned vo_ = w_common + (unsigned)(W43_WDELTA(ls) & himask);                                            \
+        const char* pb_ = MICA43_WBASE(base, off);                                                                      \
+        const unsigned vo_ = w_common + (unsigned)((delta) & himask);                                                   \
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][0]) : "v"(vo_), "s"(pb_) : "memory");              \
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(bq[set][1]) : "v"(vo_), "s"(pb_) : "memory");   \
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(bq[set][2]) : "v"(vo_), "s"(pb_) : "memory");   \
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:768" : "=v"(bq[set][3]) : "v"(vo_), "s"(pb_) : "memory");   \
     } while (0)
+#define MICA_BLOAD43_H(ps, base) MICA_BLOAD43(W43_HSET(ps), base, (ps) * psstride, (ps) == 4 ? 0 : 2 * BN * 16)
+#define MICA_BLOAD43_L(ps, base) MICA_BLOAD43(W43_LSET(ps), base, (ps) * psstride + 4 * ustride, 2 * BN * 16)
+#define W43_WAIT(N, set) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bq[set][0]), "+v"(bq[set][1]), "+v"(bq[set][2]), "+v"(bq[set][3]))
 
     // Slab DMA instruction k of this wave covers the 64 consecutive slots starting at (k * 12 + wave) * 64 of the flat LDS image
-    // [q 4][z 6][p 6][y 6][quad 4].  Issued UNCONDITIONALLY (lanes outside the volume masked by hand and zeroed explicitly; the
-    // slots 54..59 of the plan do not exist and are issued with every lane masked), so that the number of vector-memory operations
-    // in flight is a compile-time fact and the weight waits can leave the newest DMA outstanding.
+    // [q 4][z 6][p 6][y 4][quad 8].  Issued UNCONDITIONALLY (lanes outside the volume masked by hand and zeroed explicitly), so that
+    // the number of vector-memory operations in flight is a compile-time fact and the weight waits can leave the newest DMA outstanding.
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    int rel[G::DPW], meta[G::DPW];      // global byte offset within a chunk relative to the slab origin ; vy | vz << 3 | exists << 6
-#pragma unroll
-    for (int k = 0; k < G::DPW; ++k) {
-        const int ii = k * G::NW + wave;
-        const int slot = ii * 64 + lane;
-        const int q = slot / G::PLANE, rem = slot - q * G::PLANE;
-        const int vz = rem / G::PZ, r2 = rem - vz * G::PZ;
-        const int pp = r2 / G::PP, r3 = r2 - pp * G::PP;
-        const int vy = r3 >> 2, quad = r3 & 3;
-        rel[k] = ((pp * 4 + q) * Vq + (vz * d.H + vy) * Wq + quad) * 16;
-        meta[k] = vy | (vz << 3) | ((ii < G::NDMA ? 1 : 0) << 6);
-    }
+    // lane part of a DMA's source: an instruction covers 64 consecutive slots of one (plane q, slab plane vz), i.e. positions
+    // pp = 2 * part + (lane >> 5), slab rows vy = (lane >> 3) & 3 and quads lane & 7 - the same three lane terms for every
+    // instruction; (q, vz, part) are wave-uniform per instruction (w43_dma_*)
+    const int dma_vy = (lane >> 3) & 3, dma_quad = lane & 7;
+    const int dma_lane = (((lane >> 5) * 4) * Vq + dma_vy * Wq + dma_quad) * 16;
 #define MICA_SLAB_DMA43(srcbase, bufoff, k, org)                                                                        \
     do {                                                                                                                \
         const int lo_ = (bufoff) + (((k) * G::NW + wave) * 64) * 16;                                                    \
         const unsigned la_ = __builtin_amdgcn_readfirstlane(lds0 + lo_);                                                \
-        const bool ex_ = (meta[k] >> 6) != 0;                                                                           \
-        const bool ok_ = ex_ && (org).i0 + (lane & 3) < Wq && (unsigned)((org).y0 + (meta[k] & 7)) < (unsigned)d.H &&   \
-                         (unsigned)((org).z0 + ((meta[k] >> 3) & 7)) < (unsigned)d.D;                                   \
-        const int go_ = ok_ ? (org).base + rel[k] : -1;                                                                 \
+        const int ii_ = (k) * G::NW + wave;                      /* wave-uniform */                                              \
+        const int q_ = ii_ / 18, rem_ = ii_ - q_ * 18, vz_ = rem_ / 3, part_ = rem_ - vz_ * 3;                          \
+        const int sc_ = (((part_ * 2) * 4 + q_) * Vq + vz_ * d.H * Wq) * 16;                                            \
+        const bool ex_ = true;                                                                                          \
+        const bool ok_ = (org).i0 + dma_quad < Wq && (unsigned)((org).y0 + dma_vy) < (unsigned)d.H &&                   \
+                         (unsigned)((org).z0 + vz_) < (unsigned)d.D;                                                    \
+        const int go_ = ok_ ? MICA43_SLABOFF((org).base + sc_ + dma_lane) : -1;                                         \
         unsigned long long sv_;                                                                                         \
         asm volatile("s_mov_b64 %0, exec\n\tv_cmp_lt_i32 vcc, -1, %1\n\ts_mov_b64 exec, vcc\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" \
                      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                                              \
-                     : "=&s"(sv_) : "v"(go_), "s"(srcbase), "s"(la_) : "memory", "vcc", "m0");                           \
+                     : "=&s"(sv_) : "v"(go_), "s"(MICA43_SLABBASE(srcbase)), "s"(la_) : "memory", "vcc", "m0");          \
         if (ex_ && !ok_) *reinterpret_cast<uint4*>(smem + lo_ + lane * 16) = make_uint4(0, 0, 0, 0);                    \
     } while (0)
 
@@ -171,9 +212,9 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
             tz = seq / (ntx * nty);
         }
         r.tile = (tz * nty + ty) * ntx + tx;
-        r.i0 = tx * 4;
-        r.y0 = ty * 4 - 1;
-        r.z0 = tz * 4 - 1;
+        r.i0 = tx * G::QX;
+        r.y0 = ty * G::TY - 1;
+        r.z0 = tz * G::TZ - 1;
         r.base = ((r.z0 * d.H + r.y0) * Wq + r.i0) * 16;
         r.w = wwave + (int64_t)r.b * wpk_bstride * 2 + r.nb * nbstride;
         r.src0 = chunk_base_wino43(s, 0, r.b, Vq);
@@ -185,10 +226,8 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     int nitem = item + per_xcd;
     Item nxt = decode(nitem < it_end ? nitem : item);
 
-#define W43_SET(ls) ((ls) & 1)
-#define W43_NDMA(ls) ((ls) < G::DPW ? 1 : 0)
-    // prologue of the first item: slab chunk 0 -> buffer 0, weights of the wave's first step
-    MICA_BLOAD43(W43_SET(0), cur.w, 0);
+    // prologue of the first item: slab chunk 0 -> buffer 0, H fragments of the first pair-step
+    MICA_BLOAD43_H(0, cur.w);
 #pragma unroll
     for (int k = 0; k < G::DPW; ++k) MICA_SLAB_DMA43(cur.src0, 0, k, cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -226,52 +265,73 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
             Item org = cur;
             if (last) org = nxt;
             const char* wnxt = last ? nxt.w : wcur + chstride;
-#define W43_ABASE(ls) (A + a_common + (W43_ADELTA(ls) & himask) + W43_AOFF(ls))
+            // A fragment base of step st: pair steps read the hi (bc) or lo (a) planes of tap t in k-groups 0,1 and of tap t' in 2,3;
+            // the tap-8 steps read the hi planes in k-groups 0,1 and the lo planes in 2,3
+#define W43_ABASE(st) (A + a_common + (W43_KIND(st) >= 2 ? ((2 * G::PLANE * 16) & himask) + W43_AOFF_TAP(8)                                  \
+                                                         : (W43_PAIRDELTA(W43_PS(st)) & himask) + W43_AOFF_TAP(2 * W43_PS(st)) +                \
+                                                           (W43_KIND(st) == 0 ? 2 * G::PLANE * 16 : 0)))
 #define W43_AFRAG(base, f) (*reinterpret_cast<const half8*>((base) + (f) * G::PZ * 16))
             const char* ab_cur = W43_ABASE(0);
-            constexpr int AD = 3;
+            constexpr int AD = 2;                        // A fragments requested ahead (each feeds 4 or 8 MFMAs)
             half8 ar[AD + 1];
 #pragma unroll
             for (int i = 0; i < AD; ++i) ar[i] = W43_AFRAG(ab_cur, i);
 #pragma unroll
-            for (int ls = 0; ls < NS; ++ls) {
-                half8 (&bc)[NCT] = bq[W43_SET(ls)];
-                if (ls + 1 < NS) MICA_BLOAD43(W43_SET(ls + 1), wcur, ls + 1);
-                else MICA_BLOAD43(W43_SET(0), wnxt, 0);
-                // in flight and NEWER than this step's fragments: the four loads just issued plus the previous step's slab DMA
-                const int newer = NCT + (ls >= 1 ? W43_NDMA(ls - 1) : 0);
-                if (newer == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
-                else asm volatile("s_waitcnt vmcnt(5)" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[2]), "+v"(bc[3]));
+            for (int st = 0; st < NS; ++st) {
+                const int ps = W43_PS(st), kind = W43_KIND(st);
+                // requests of this step, then the wait for the fragments it uses (in flight and NEWER than those: what was just
+                // requested, the fragments requested with them, and the slab DMAs issued since)
+                if (kind == 0) {
+                    MICA_BLOAD43_L(ps, wcur);
+                    if (ps == 0) MICA_BLOAD43_H(1, wcur); else if (ps == 1) MICA_BLOAD43_H(2, wcur); else if (ps == 2) MICA_BLOAD43_H(3, wcur); else MICA_BLOAD43_H(4, wcur);
+                    if (W43_NDMA(st - 2) + W43_NDMA(st - 1) == 0) W43_WAIT(8, W43_HSET(ps)); else W43_WAIT(10, W43_HSET(ps));
+                } else if (kind == 1) {
+                    if (W43_NDMA(st - 1)) W43_WAIT(5, W43_LSET(ps)); else W43_WAIT(4, W43_LSET(ps));
+                } else if (kind == 2) {
+                    MICA_BLOAD43_L(4, wcur);
+                    MICA_BLOAD43_H(0, wnxt);
+                    W43_WAIT(8, W43_HSET(4));
+                } else {
+                    W43_WAIT(4, W43_LSET(4));
+                }
+                static_assert(G::DPW <= 6, "DMAs are issued in the steps a0 .. bc2; the wait immediates above assume that");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < W43_NDMA(ls); ++q) MICA_SLAB_DMA43(nsrc, nxt_off, ls + q, org);
+                for (int q = 0; q < W43_NDMA(st); ++q) MICA_SLAB_DMA43(nsrc, nxt_off, st + q, org);
                 const char* ab_nxt = ab_cur;
-                if (ls + 1 < NS) ab_nxt = W43_ABASE(ls + 1);
+                if (st + 1 < NS) ab_nxt = W43_ABASE(st + 1);
+                half8 (&b1)[NCT] = bq[kind == 3 ? W43_LSET(4) : W43_HSET(ps)];
+                half8 (&b2)[NCT] = bq[W43_LSET(ps)];
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
-                    const int fi = ls * NF + f;                 // fragment index within the chunk; lives in ar[fi % (AD + 1)]
+                    const int fi = st * NF + f;                 // fragment index within the chunk; lives in ar[fi % (AD + 1)]
                     if (f + AD < NF) ar[(fi + AD) % (AD + 1)] = W43_AFRAG(ab_cur, f + AD);
-                    else if (ls + 1 < NS) ar[(fi + AD) % (AD + 1)] = W43_AFRAG(ab_nxt, f + AD - NF);
+                    else if (st + 1 < NS) ar[(fi + AD) % (AD + 1)] = W43_AFRAG(ab_nxt, f + AD - NF);
 #pragma unroll
                     for (int c = 0; c < NCT; ++c)
-                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(ar[fi % (AD + 1)]), "v"(bc[c]));
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(ar[fi % (AD + 1)]), "v"(b1[c]));
+                    if (kind == 1) {
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c)
+                            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(ar[fi % (AD + 1)]), "v"(b2[c]));
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 ab_cur = ab_nxt;
             }
 #undef W43_ABASE
 #undef W43_AFRAG
-            // the slab DMAs of this chunk are older than the four weight loads still wanted in flight
+            // the slab DMAs of this chunk are older than the four weight loads (the next chunk's first H) still wanted in flight
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __syncthreads();
             par ^= 1;
             wcur = wnxt;
         }
-        // the next item's first weight fragments were requested a step ago: retire them here (the compiler cannot see them in flight)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]));
+        // the next item's first weight fragments were requested two steps ago: retire them here (the compiler cannot see them in flight)
+        W43_WAIT(0, W43_HSET(0));
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU/LDS readers
 
-        // ---- output transform through the idle slab buffer: four passes of 32 columns; T = [z 4][p 6][row 16 = y*4+quad][32 + 4] floats ----
+        // ---- output transform through the idle slab buffer: four passes of 32 columns; T = [z 4][p 6][row 16 = y*8+quad][32 + 4] floats ----
         {
             constexpr int CP = 32, RS = CP + 4, REG = 16 * RS;
             static_assert(4 * 6 * REG * 4 <= G::CH_BYTES, "epilogue fits one slab buffer");
@@ -281,21 +341,24 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
             const int nnitem = nitem + per_xcd;
             const Item nn = decode(nnitem < it_end ? nnitem : (has_next ? nitem : item));
             const int fz = wave & 3, fch = (wave >> 2) & 1;          // finishing role of waves 0..7: z plane, 16-column half
-            const int frow = lane >> 2, fcg = lane & 3;
+            int elane = lane;
+            asm volatile("" : "+v"(elane));      // per item: keeps the epilogue's lane-dependent addresses from being hoisted over (and kept live through) the main loop
+            const int frow = elane >> 2, fcg = elane & 3;
+            const int elr = elane & 15, elg = elane >> 4;
             const int P = (items_per_b / nnb) * 4;
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
+            for (int pass = 0; pass < MICA43_EPI_PASSES; ++pass) {
                 const int c0 = (pass >> 1) * 2;                      // first column tile of the pass
                 const int wq = pass & 1;                             // the channel half (wave group) that writes T
                 if (wn == wq) {
-                    // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg  ->  row = y*4 + quad: y = lane >> 4, quad = reg
+                    // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg = y*8 + quad of the fragment
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
                         float* dst = xs + (f * 6 + wp) * REG;
 #pragma unroll
                         for (int c = 0; c < 2; ++c)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) dst[(lg * 4 + i) * RS + c * 16 + lr] = acc[f][c0 + c][i];
+                            for (int i = 0; i < 4; ++i) dst[(elg * 4 + i) * RS + c * 16 + elr] = acc[f][c0 + c][i];
                     }
                 }
                 __syncthreads();
@@ -322,7 +385,7 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                         yv[2][c] = (s12 + 4.f * s34) * out_scale + bb[c];
                         yv[3][c] = (d12 + 8.f * d34 + a5[c]) * out_scale + bb[c];
                     }
-                    const int gx = (tx * 4 + (frow & 3)) * 4, gy = ty * 4 + (frow >> 2), gz = tz * 4 + fz;
+                    const int gx = (tx * G::QX + (frow & (G::QX - 1))) * 4, gy = ty * G::TY + frow / G::QX, gz = tz * G::TZ + fz;
                     // statistics: sums of (v - shift), (v - shift)^2 with one shift per channel for the whole wave (the tile's first voxel)
                     float sk[4];
 #pragma unroll
@@ -386,14 +449,17 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #undef MICA_BLOAD43
 #undef MICA_SLAB_DMA43
     // nothing may still be in flight towards this workgroup's registers or LDS when it ends
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]));
-#undef W43_SET
+    W43_WAIT(0, W43_HSET(0));
+#undef MICA_BLOAD43_H
+#undef MICA_BLOAD43_L
+#undef W43_WAIT
 #undef W43_NDMA
-#undef W43_TAP
-#undef W43_AOFF
-#undef W43_ADELTA
-#undef W43_WOFF
-#undef W43_WDELTA
+#undef W43_PS
+#undef W43_KIND
+#undef W43_HSET
+#undef W43_LSET
+#undef W43_AOFF_TAP
+#undef W43_PAIRDELTA
 }
 
 bool conv_wino43_eligible(int cout) { return cout % 128 == 0; }
@@ -402,9 +468,11 @@ bool conv_wino43_eligible(int cout) { return cout % 128 == 0; }
 int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out,
                        int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
     if (!conv_wino43_eligible(cout)) { fprintf(stderr, "conv_wino43: cout must be a multiple of 128\n"); abort(); }
+    if ((int64_t)d.D * d.H * ((d.W + 3) / 4) * 24 * 16 >= (1ll << 31)) { fprintf(stderr, "conv_wino43: tile too large for 32-bit slab offsets\n"); abort(); }
     int total = 0;
     for (int i = 0; i < s.n; ++i) total += s.chunks[i];
-    const int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / 128;
+    const int ntx = (d.W + 4 * Geo43::QX - 1) / (4 * Geo43::QX), nty = (d.H + Geo43::TY - 1) / Geo43::TY, ntz = (d.D + Geo43::TZ - 1) / Geo43::TZ,
+              nnb = cout / 128;
     const size_t lds = 2 * Geo43::CH_BYTES;
     static unsigned long long seen = 0;
     static int cus_of[64] = {0};

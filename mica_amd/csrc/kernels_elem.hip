@@ -152,6 +152,9 @@ int64_t fused_stats_ws_floats(int B, int S) {
     int64_t dwp = ((int64_t)S * S * ((S + 7) / 8) + 31) / 32 * 256 * 3;   // depthwise: one partial per 32 x-runs, C <= 256
     int64_t m = a > bb ? a : bb;
     if (dwp > m) m = dwp;
+    // conv_wino43 (kernels_conv43.hip): 4 partials per 32x2x4 output tile, Cout <= 512
+    const int64_t t43 = (int64_t)((S + 31) / 32) * ((S + 1) / 2) * ((S + 3) / 4) * 4 * 512 * 3;
+    if (t43 > m) m = t43;
     return m * B;
 }
 

@@ -23,7 +23,9 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 class Engine:
-    def __init__(self, device: int | str | torch.device = 0, max_batch: int = 1, tile_size: int = 64):
+    def __init__(self, device: int | str | torch.device = 0, max_batch: int = 1, tile_size: int = 64, conv_variant: int | None = None):
+        """conv_variant: None = the library default (encoder.2's 3x3x3 convs on the F(4,3) kernel; MICA_F43=0 in the environment turns
+        that off), 0 = every 3x3x3 conv on the F(2,3) kernel, 1 = encoder.2 on F(4,3).  Fixed before the weights are loaded."""
         if not torch.cuda.is_available():
             raise MicaHipError("no HIP device visible: mica_amd runs on MI355X (gfx950) only, there is no CPU fallback")
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
@@ -38,6 +40,9 @@ class Engine:
         if r != 0:
             raise MicaHipError(f"mica_create failed ({r}): {self.lib.mica_last_error(None).decode()}")
         self._h = h
+        if conv_variant is not None:
+            self._check(self.lib.mica_set_conv_variant(self._h, int(conv_variant)), "mica_set_conv_variant")
+        self.conv_variant = int(self.lib.mica_get_conv_variant(self._h))
         self.weights_loaded = False
         self.last_forward_scale = 16.0     # lowest activation scale any chunk of the last forward_* call needed
         self.forward_retries = 0           # chunks of the last forward_* call that had to repeat a tile at a lower scale
@@ -331,18 +336,19 @@ class Engine:
         return dis, mat
 
     # -- single ops (tests) -----------------------------------------------------------------------------
-    def op_conv3d(self, x, w, b, k):
+    def op_conv3d(self, x, w, b, k, variant: int = 0):
+        """variant 0: the F(2,3)-along-x kernel (and the 1x1 kernel for k = 1); 1: the F(4,3)-along-x kernel (k = 3, cout % 128 == 0)."""
         x = _f32c(x, "x")
         B, cin, d, h, ww = x.shape
         w = np.ascontiguousarray(w, dtype=np.float32)
         b = np.ascontiguousarray(b, dtype=np.float32)
         cout = w.shape[0]
         y = torch.empty((B, cout, d, h, ww), dtype=torch.float32, device=self.device)
-        self._check(self.lib.mica_op_conv3d(self._h, _ptr(x), B, cin, d, h, ww, w.ctypes.data_as(_cabi._FP),
-                                            b.ctypes.data_as(_cabi._FP), cout, k, _ptr(y), self._stream()), "mica_op_conv3d")
+        self._check(self.lib.mica_op_conv3d_variant(self._h, _ptr(x), B, cin, d, h, ww, w.ctypes.data_as(_cabi._FP),
+                                                    b.ctypes.data_as(_cabi._FP), cout, k, int(variant), _ptr(y), self._stream()), "mica_op_conv3d")
         return y
 
-    def op_norm_conv1_conv3(self, x, w1, b1, w3, b3):
+    def op_norm_conv1_conv3(self, x, w1, b1, w3, b3, variant: int = 0):
         """conv3x3x3(conv1x1x1(relu(instance_norm(x)))) through the fused 1x1 kernel (raw source, Winograd-operand epilogue)."""
         x = _f32c(x, "x")
         B, cin, d, h, ww = x.shape
@@ -350,8 +356,8 @@ class Engine:
         cmid, cout = w1.shape[0], w3.shape[0]
         y = torch.empty((B, cout, d, h, ww), dtype=torch.float32, device=self.device)
         fp = lambda a: a.ctypes.data_as(_cabi._FP)
-        self._check(self.lib.mica_op_norm_conv1_conv3(self._h, _ptr(x), B, cin, d, h, ww, fp(w1), fp(b1), cmid, fp(w3), fp(b3), cout, _ptr(y),
-                                                      self._stream()), "mica_op_norm_conv1_conv3")
+        self._check(self.lib.mica_op_norm_conv1_conv3_variant(self._h, _ptr(x), B, cin, d, h, ww, fp(w1), fp(b1), cmid, fp(w3), fp(b3), cout,
+                                                              int(variant), _ptr(y), self._stream()), "mica_op_norm_conv1_conv3")
         return y
 
     def op_instnorm_relu(self, x):

@@ -68,7 +68,7 @@ def synth_af_clustered(shape, seed: int, centres) -> np.ndarray:
 
 
 def stress_case(kind: str, S: int):
-    """Inputs of the round-4 stress goldens (oracle/gen_golden_r4.py, tests/golden/r4_*): -> (weights dict, map float32
+    """Inputs of the round-4 stress goldens (tests/golden/r4_*, generator: gen_golden_r4.py): -> (weights dict, map float32
     [1,1,S,S,S], AF3 encodings float32 [1,24,S,S,S]).  kind 'heavy' = heavy-tailed weights on uniform density with Bernoulli
     encodings; 'blob' = the default weights on a normaliser-shaped map (> 80 % zeros, blobs reaching 1.0) with encodings
     clustered as residues at the blob centres."""

@@ -68,6 +68,71 @@ def test_fused_norm_conv1x1_into_winograd_conv(eng, cin, cmid, cout, dims, batch
     assert rel_err(got, ref) < RTOL
 
 
+@pytest.mark.parametrize("cin,cout,dims,batch", [
+    (16, 128, (8, 8, 8), 1),                # one chunk, one tile per z/y block, W = 8 (two quads)
+    (32, 128, (4, 4, 16), 2),               # exactly one tile per batch entry
+    (256, 128, (8, 8, 16), 2),              # encoder.2 conv1's channels at S = 16-like sizes
+    (384, 128, (6, 10, 20), 1),             # 24 chunks, ragged tiles in y and z, W = 20 (5 quads: two x tiles, the second ragged)
+    (64, 256, (5, 7, 9), 2),                # W = 9: a ragged quad (zero padded operand), two channel blocks
+    (40, 512, (12, 6, 18), 1),              # padded last chunk (Cin = 40), four channel blocks
+    (72, 128, (16, 32, 16), 1),             # the blocked tile walk (nty = 8, ntz = 4)
+    (130, 256, (3, 64, 64), 1),             # production width, items > workgroups
+    (3, 128, (1, 1, 1), 3),                 # a single voxel
+    (48, 128, (2, 3, 66), 1),               # W > 64
+])
+def test_conv3d_winograd_f43_kernel(eng, cin, cout, dims, batch):
+    """conv_wino43_kernel (kernels_conv43.hip: Winograd F(4,3) along x, the kernel of encoder.2's convs) as a single op against
+    torch's conv3d: operand producer, weight packer, 6-position slab, output transform, ragged tiles, persistent item walk."""
+    x = _rand((batch, cin, *dims), 31)
+    w = _rand((cout, cin, 3, 3, 3), 32) * (3.0 / (cin * 27)) ** 0.5
+    b = _rand((cout,), 33) * 0.1
+    ref = F.conv3d(x, w, b, padding=1)
+    got = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3, variant=1)
+    assert rel_err(got, ref) < RTOL
+
+
+def test_conv3d_winograd_f43_asymmetric_identity_and_precision(eng):
+    """Delta inputs with asymmetric weights (transposed operand / C-D maps, position or tap mix-ups show at once), then the
+    accuracy of the F(4,3) arithmetic on a deep layer against float64: about 4x the F(2,3) kernel's error, still fp32-grade."""
+    x = torch.zeros((1, 16, 8, 8, 16))
+    x[0, 3, 2, 5, 7] = 1.0
+    x[0, 11, 6, 1, 12] = -2.0
+    x[0, 5, 0, 0, 0] = 0.5
+    x[0, 7, 7, 7, 15] = 3.0
+    w = torch.arange(128 * 16 * 27, dtype=torch.float32).reshape(128, 16, 3, 3, 3) / 4000.0
+    b = torch.arange(128, dtype=torch.float32)
+    ref = F.conv3d(x, w, b, padding=1)
+    got = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3, variant=1)
+    assert rel_err(got, ref) < 2e-5
+    x = _rand((1, 512, 8, 8, 16), 5, 0.0, 4.0)
+    w = _rand((256, 512, 3, 3, 3), 6) * 0.02
+    b = torch.zeros(256)
+    ref64 = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    e43 = float((eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3, variant=1).cpu().double() - ref64).abs().max() / ref64.abs().max())
+    e23 = float((eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3, variant=0).cpu().double() - ref64).abs().max() / ref64.abs().max())
+    print(f"512->256 vs float64: F(4,3) {e43:.2e}, F(2,3) {e23:.2e}")
+    assert e43 < 1.5e-5 and e23 < 2e-6
+
+
+@pytest.mark.parametrize("cin,cmid,cout,dims,batch", [
+    (512, 256, 512, (4, 4, 16), 1),         # encoder.2's dual_attn.fusion -> transition: four epilogue passes, F(4,3) operand emitted
+    (128, 64, 128, (8, 8, 8), 2),           # W = 8
+    (256, 128, 128, (3, 5, 64), 1),         # W = 64 (the production width), ragged last tile
+    (64, 64, 128, (6, 5, 9), 2),            # W = 9 does not divide the tile: raw output + the F(4,3) operand pass
+    (64, 64, 128, (2, 2, 4), 3),            # W = 4: one quad per row
+])
+def test_fused_norm_conv1x1_into_winograd_f43_conv(eng, cin, cmid, cout, dims, batch):
+    """The 1x1 kernel's F(4,3) epilogue (kernels_conv1x1.hip, WINO = 2) feeding conv_wino43_kernel."""
+    x = _rand((batch, cin, *dims), 21) * 2.0 + 0.5
+    w1 = _rand((cmid, cin, 1, 1, 1), 22) * (3.0 / cin) ** 0.5
+    b1 = _rand((cmid,), 23) * 0.1
+    w3 = _rand((cout, cmid, 3, 3, 3), 24) * (3.0 / (cmid * 27)) ** 0.5
+    b3 = _rand((cout,), 25) * 0.1
+    ref = F.conv3d(F.conv3d(F.relu(F.instance_norm(x, eps=1e-5)), w1, b1), w3, b3, padding=1)
+    got = eng.op_norm_conv1_conv3(x.cuda(), w1.numpy().reshape(cmid, cin), b1.numpy(), w3.numpy(), b3.numpy(), variant=1)
+    assert rel_err(got, ref) < RTOL
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_conv3d_persistent_schedule_odd_shapes(eng, seed):
     """The persistent conv distributes (batch, tile, channel block) items over one workgroup per CU: item counts below,

@@ -11,6 +11,7 @@ if len(sys.argv) >= 4:
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 zero = os.environ.get('ZERO', '0') == '1'
+variant = int(os.environ.get('VARIANT', '0'))      # 1: the F(4,3) kernel (cout % 128 == 0)
 e = Engine(0, max_batch=1, tile_size=16)
 for cin, cout, k in shapes:
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -21,6 +22,6 @@ for cin, cout, k in shapes:
         x = torch.zeros_like(x); w = np.zeros_like(w)
     e.set_profiling(False)
     for _ in range(reps):
-        y = e.op_conv3d(x, w, b, k)
+        y = e.op_conv3d(x, w, b, k, variant=variant if k == 3 else 0)
     torch.cuda.synchronize()
     print(f"conv {cin}->{cout} k={k} S={S}: done, out mean {float(y.mean()):.5f}", flush=True)
