@@ -259,18 +259,7 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
                         dv[k][4] = ok ? c.x : 0.f; dv[k][5] = ok ? c.y : 0.f; dv[k][6] = ok ? c.z : 0.f; dv[k][7] = ok ? c.w : 0.f;
                     }
                     float t[6][8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float d0 = dv[0][j], d1 = dv[1][j], d2 = dv[2][j], d3 = dv[3][j], d4 = dv[4][j], d5 = dv[5][j];
-                        t[0][j] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
-                        const float e = fmaf(-4.f, d2, d4), o = fmaf(-4.f, d1, d3);
-                        t[1][j] = e + o;
-                        t[2][j] = e - o;
-                        const float e2 = d4 - d2, o2 = 2.f * (d3 - d1);
-                        t[3][j] = e2 + o2;
-                        t[4][j] = e2 - o2;
-                        t[5][j] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
-                    }
+                    wino43_input_transform(dv, t);
                     const int chunk = pass * 4 + (kg >> 1), kh = kg & 1;
                     const int64_t ph = (int64_t)(vrow / d.W) * Wq + i;
                     _Float16* wbp = wino.p + (((int64_t)b * wino.chunks_total + wino.chunk_off + chunk) * (int64_t)Vq) * 192;

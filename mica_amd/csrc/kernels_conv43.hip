@@ -10,16 +10,17 @@
 // 27 x 256..512 per output, late in the network) the result is indistinguishable from F(2,3) everywhere.  Those four layers run here.
 // Replaces nn.Conv3d(k=3, padding=1) of reference models/model.py:107,115,122,142 (encoder.2).
 //
-//   points {0, 1, -1, 2, -2, inf}; per output quad (x = 4i .. 4i+3), d_k = in(4i-1+k), k = 0..5 (zero outside the volume):
-//     t0 = 4 d0 - 5 d2 + d4            u0 = g0/4                               y0 = m0 + m1 + m2 +  m3 +  m4
-//     t1 = -4 d1 - 4 d2 + d3 + d4      u1 = -(g0 + g1 + g2)/6                  y1 =      m1 - m2 + 2m3 - 2m4
-//     t2 =  4 d1 - 4 d2 - d3 + d4      u2 = -(g0 - g1 + g2)/6                  y2 =      m1 + m2 + 4m3 + 4m4
-//     t3 = -2 d1 -   d2 + 2 d3 + d4    u3 = g0/24 + g1/12 + g2/6               y3 =      m1 - m2 + 8m3 - 8m4 + m5
-//     t4 =  2 d1 -   d2 - 2 d3 + d4    u4 = g0/24 - g1/12 + g2/6               m_p = sum over (dz, dy, cin) of t_p u_p
-//     t5 =  4 d1 - 5 d3 + d5           u5 = g2
-//   The producer passes (prep_wino43_kernel below, the F(4,3) epilogue of conv1x1_kernel) do the input transform in f32 and
-//   encode t * (ascale / 4) as f16 hi + lo (|t| <= 10 max|d|: a quarter of the scale keeps the f16 range of the F(2,3) operand
-//   to within 2.5x; powers of two, exact); the weight packer does the weight transform in f64.
+//   points {0, a, -a, b, -b, inf} with a = 3/2, b = 2/3 (a b = 1; s = a^2 + b^2); per output quad (x = 4i .. 4i+3),
+//   d_k = in(4i-1+k), k = 0..5 (zero outside the volume):
+//     t0 = d0 - s d2 + d4                          u0 = g0                                    y0 = m0 + m1 + m2 + m3 + m4
+//     t1,2 = (d4 - b^2 d2) +- (a d3 - b d1)        u1,2 = (g0 +- a g1 + a^2 g2) / N_a         y1 = a (m1 - m2) + b (m3 - m4)
+//     t3,4 = (d4 - a^2 d2) +- (b d3 - a d1)        u3,4 = (g0 +- b g1 + b^2 g2) / N_b         y2 = a^2 (m1 + m2) + b^2 (m3 + m4)
+//     t5 = d1 - s d3 + d5                          u5 = g2                                    y3 = a^3 (m1 - m2) + b^3 (m3 - m4) + m5
+//     N_a = 2 a^2 (a^2 - b^2), N_b = 2 b^2 (b^2 - a^2);   m_p = sum over (dz, dy, cin) of t_p u_p
+//   (the textbook points {0, +-1, +-2} make m5 four times the output's magnitude: 0.77e-6 rms error per layer against 0.55e-6 here,
+//   common.h).  The producer passes (prep_wino43_kernel below, the F(4,3) epilogue of conv1x1_kernel) do the input transform in f32
+//   and encode t * (ascale / 4) as f16 hi + lo (|t| <= 5.4 max|d|; powers of two, exact); the weight packer does the weight
+//   transform in f64.
 //
 // Operand ("wino43") layout:  _Float16 [B][chunks][6 p][4 q][Vq][8],  Vq = D*H*ceil(W/4); q = hi|lo x channel half of the chunk.
 //
@@ -98,12 +99,44 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                                                           Dims d, int cout, int total_chunks, int ntx, int nty, int nnb,
                                                           int items_per_b, int total_items, float* __restrict__ stats_ws) {
     using G = Geo43;
-    constexpr int BN = G::BN, NCT = 4, NS = 10, NF = 4;      // NS: steps per chunk (4 x (a, bc) + x + y)
+    constexpr int BN = G::BN, NCT = 4, NS = 14, NF = 4;      // NS: steps per chunk (4 x (a, b, c) + x + y)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave % 6, wn = wave / 6;
+    // Soft chunk synchronisation (-DMICA43_SOFT; an experiment that did not pay).  A workgroup barrier per chunk couples twelve waves
+    // whose weight fragments and slab DMAs arrive at different times: without any synchronisation (results wrong) the kernel ran 8 %
+    // faster, with operands served from L1 / L2 the barrier cost 1 % (tools/exp/abl43.sh).  Here what the barrier guards is split
+    // into two counters in LDS with slack - and the kernel is 4 % slower than with the barrier, whatever the slack: the gain of the
+    // unsynchronised build comes from waves drifting many chunks apart, not from per-chunk jitter.
+    //   landed : += 1 by each wave in step 9, once its slab DMAs for the next chunk are in LDS (they were issued in steps 3..5 and are
+    //            older than the weight fragments that step has just waited for); a wave enters chunk c + 1 when landed >= 12 (c + 1)
+    //   done   : += 1 by each wave when its last LDS read of a chunk has returned; a wave issues its first slab DMA of chunk c (step
+    //            3, into the buffer that chunk c - 1 read) when done >= 12 c
+    // Every wait points at an earlier program point of the other waves, so there is no cycle; the last chunk of an item ends in
+    // the workgroup barrier as before (the epilogue needs one anyway) and the counters restart from zero per item.  The polls are
+    // bounded: a bookkeeping error must show up as a failed test, not as a hung GPU.
+    unsigned* sync_ctr = reinterpret_cast<unsigned*>(smem + 2 * Geo43::CH_BYTES);      // [0] landed, [1] done
+#ifdef MICA43_SOFT
+#define W43_SOFT 1
+#else
+#define W43_SOFT 0          /* measured 4 % SLOWER than the barrier at every slack (DMAs from step 1, 3, 6 or 8): off; kept as a switch */
+#endif
+    bool soft_broken = false;
+    auto soft_wait = [&](int which, unsigned target) {
+        if (soft_broken) return;
+        for (int spin = 0; spin < (1 << 14); ++spin) {                     // legitimate waits are a fraction of a chunk (microseconds)
+            const unsigned v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(sync_ctr + which));
+            if (v >= target) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        soft_broken = true;                                                // give up for good: wrong numbers, no hang
+    };
+    auto soft_signal = [&](int which) {
+        if (lane == 0) atomicAdd(sync_ctr + which, 1u);
+    };
+    if (tid == 0) { sync_ctr[0] = 0; sync_ctr[1] = 0; }
     const int Wq = (d.W + 3) >> 2;
     const int V = d.D * d.H * d.W, Vq = d.D * d.H * Wq;
 
@@ -130,23 +163,31 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     // Weight fragments and the step schedule.  The three split products of a tap pair (t, t') are grouped so that operands are
     // shared between MFMAs:  with  Ahi = [a_hi(t) | a_hi(t')], Alo = [a_lo(t) | a_lo(t')]  (k-groups 0,1 = the two channel halves at
     // tap t, 2,3 at tap t') and  H = [b_hi(t) ; b_hi(t')], L = [b_lo(t) ; b_lo(t')]:
-    //     step a  : Alo . H                    (16 MFMAs per wave)
-    //     step bc : Ahi . H  and  Ahi . L      (32 MFMAs: every A fragment feeds 8)
+    //     step a : Alo . H        step b : Ahi . H        step c : Ahi . L        (16 MFMAs per wave each)
     // and tap 8, which has no partner:  x: [a_hi(8) | a_lo(8)] . [b_hi(8) ; b_hi(8)],  y: the same A . [b_lo(8) ; 0].
-    // Per chunk that is 10 weight-fragment sets and 40 A-fragment reads for the same 224 MFMAs that the X / X' / Y grouping of
-    // conv_wino16_kernel feeds with 14 and 56: this kernel's weight fragments feed 4 MFMAs each (8 there), and with 14 sets per
-    // chunk their loads alone kept the vector L1 busy for as long as the MFMAs take (12 waves x 56 KiB per chunk at 64 B/clk).
+    // Per chunk that is 10 weight-fragment sets for the same 224 MFMAs that the X / X' / Y grouping of conv_wino16_kernel feeds
+    // with 14: this kernel's weight fragments feed 4 MFMAs each (8 there), and with 14 sets per chunk their loads alone kept the
+    // vector L1 busy for as long as the MFMAs take (12 waves x 56 KiB per chunk at 64 B/clk).
     // Three register sets hold the fragments: H of pair-step ps in set {0,1,0,1,2}[ps], L in {2,2,2,0,1}[ps] - after the five
-    // pair-steps of a chunk the assignment is back where it started, so every index is a compile-time constant; H is requested
-    // three steps (48 MFMAs) ahead, L one step.
+    // pair-steps of a chunk the assignment is back where it started, so every index is a compile-time constant.  Both are
+    // requested at the start of step a: L of this pair-step (used two steps later, in c) and H of the NEXT pair-step (three steps).
     half8 bq[3][NCT];
-#define W43_PS(st) ((st) < 8 ? (st) / 2 : 4)
-#define W43_KIND(st) ((st) < 8 ? (st) & 1 : (st) - 6)          /* 0 a, 1 bc, 2 x, 3 y */
+#define W43_PS(st) ((st) < 12 ? (st) / 3 : 4)
+#define W43_KIND(st) ((st) < 12 ? (st) % 3 : (st) - 9)         /* 0 a, 1 b, 2 c, 3 x, 4 y */
 #define W43_HSET(ps) ((ps) == 4 ? 2 : (ps) & 1)
 #define W43_LSET(ps) ((ps) < 3 ? 2 : (ps) == 3 ? 0 : 1)
 #define W43_AOFF_TAP(tap) ((((tap) / 3) * G::PZ + ((tap) % 3) * G::QX) * 16)
 #define W43_PAIRDELTA(ps) ((ps) == 1 ? (G::PZ - 2 * G::QX) * 16 : G::QX * 16)
-#define W43_NDMA(st) ((st) >= 0 && (st) < G::DPW ? 1 : 0)
+    // the six slab DMAs of a chunk go out two per step in steps 3, 4, 5 (measured flat between "all in step 0" and "one per step"):
+    // late enough that the waves still finishing the PREVIOUS chunk are rarely waited for (W43_SOFT below), early enough to land
+#ifdef MICA43_DMA_FIRST
+#define W43_DMA_FIRST MICA43_DMA_FIRST
+#else
+#define W43_DMA_FIRST 3
+#endif
+#define W43_LANDED_STEP (W43_DMA_FIRST + 3 <= 9 ? 9 : 12)      /* a step whose weight wait covers loads issued after the last DMA */
+#define W43_NDMA(st) ((st) >= W43_DMA_FIRST && ((st) - W43_DMA_FIRST) * 2 < G::DPW ? 2 : 0)
+#define W43_DMA0(st) (((st) - W43_DMA_FIRST) * 2)
     // one fragment set: four 16-cout column tiles, 256 B apart; `delta` (bytes, applied to k-groups 2,3) selects the second tap's units
 #define MICA_BLOAD43(set, base, off, delta)                                                                             \
     do {                                                                                                                \
@@ -160,6 +201,15 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #define MICA_BLOAD43_H(ps, base) MICA_BLOAD43(W43_HSET(ps), base, (ps) * psstride, (ps) == 4 ? 0 : 2 * BN * 16)
 #define MICA_BLOAD43_L(ps, base) MICA_BLOAD43(W43_LSET(ps), base, (ps) * psstride + 4 * ustride, 2 * BN * 16)
 #define W43_WAIT(N, set) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bq[set][0]), "+v"(bq[set][1]), "+v"(bq[set][2]), "+v"(bq[set][3]))
+    // wait until at most n (a compile-time constant after unrolling, 4 .. 14) vector-memory operations are outstanding
+#define W43_WAITN(n, set)                                                                                               \
+    do {                                                                                                                \
+        static_assert((n) >= 4 && (n) <= 14, "wait immediates");                                                        \
+        if ((n) == 4) W43_WAIT(4, set); else if ((n) == 5) W43_WAIT(5, set); else if ((n) == 6) W43_WAIT(6, set);       \
+        else if ((n) == 7) W43_WAIT(7, set); else if ((n) == 8) W43_WAIT(8, set); else if ((n) == 9) W43_WAIT(9, set);  \
+        else if ((n) == 10) W43_WAIT(10, set); else if ((n) == 11) W43_WAIT(11, set); else if ((n) == 12) W43_WAIT(12, set); \
+        else if ((n) == 13) W43_WAIT(13, set); else W43_WAIT(14, set);                                                  \
+    } while (0)
 
     // Slab DMA instruction k of this wave covers the 64 consecutive slots starting at (k * 12 + wave) * 64 of the flat LDS image
     // [q 4][z 6][p 6][y 4][quad 8].  Issued UNCONDITIONALLY (lanes outside the volume masked by hand and zeroed explicitly), so that
@@ -267,12 +317,12 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
             const char* wnxt = last ? nxt.w : wcur + chstride;
             // A fragment base of step st: pair steps read the hi (bc) or lo (a) planes of tap t in k-groups 0,1 and of tap t' in 2,3;
             // the tap-8 steps read the hi planes in k-groups 0,1 and the lo planes in 2,3
-#define W43_ABASE(st) (A + a_common + (W43_KIND(st) >= 2 ? ((2 * G::PLANE * 16) & himask) + W43_AOFF_TAP(8)                                  \
+#define W43_ABASE(st) (A + a_common + (W43_KIND(st) >= 3 ? ((2 * G::PLANE * 16) & himask) + W43_AOFF_TAP(8)                                  \
                                                          : (W43_PAIRDELTA(W43_PS(st)) & himask) + W43_AOFF_TAP(2 * W43_PS(st)) +                \
                                                            (W43_KIND(st) == 0 ? 2 * G::PLANE * 16 : 0)))
 #define W43_AFRAG(base, f) (*reinterpret_cast<const half8*>((base) + (f) * G::PZ * 16))
             const char* ab_cur = W43_ABASE(0);
-            constexpr int AD = 2;                        // A fragments requested ahead (each feeds 4 or 8 MFMAs)
+            constexpr int AD = 3;                        // A fragments requested ahead (each feeds 4 MFMAs)
             half8 ar[AD + 1];
 #pragma unroll
             for (int i = 0; i < AD; ++i) ar[i] = W43_AFRAG(ab_cur, i);
@@ -284,24 +334,39 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                 if (kind == 0) {
                     MICA_BLOAD43_L(ps, wcur);
                     if (ps == 0) MICA_BLOAD43_H(1, wcur); else if (ps == 1) MICA_BLOAD43_H(2, wcur); else if (ps == 2) MICA_BLOAD43_H(3, wcur); else MICA_BLOAD43_H(4, wcur);
-                    if (W43_NDMA(st - 2) + W43_NDMA(st - 1) == 0) W43_WAIT(8, W43_HSET(ps)); else W43_WAIT(10, W43_HSET(ps));
-                } else if (kind == 1) {
-                    if (W43_NDMA(st - 1)) W43_WAIT(5, W43_LSET(ps)); else W43_WAIT(4, W43_LSET(ps));
+                    // H of this pair-step was requested a pair-step ago, in front of the DMAs of three steps and of the eight loads just issued
+                    if (st == 0) W43_WAITN(8, W43_HSET(0)); else if (st == 3) W43_WAITN(8 + W43_NDMA(0) + W43_NDMA(1) + W43_NDMA(2), W43_HSET(1));
+                    else if (st == 6) W43_WAITN(8 + W43_NDMA(3) + W43_NDMA(4) + W43_NDMA(5), W43_HSET(2));
+                    else W43_WAITN(8 + W43_NDMA(6) + W43_NDMA(7) + W43_NDMA(8), W43_HSET(3));
                 } else if (kind == 2) {
+                    // L of this pair-step was requested two steps ago, in front of the next H and the DMAs of steps a and b
+                    if (st == 2) W43_WAITN(4 + W43_NDMA(0) + W43_NDMA(1), W43_LSET(0)); else if (st == 5) W43_WAITN(4 + W43_NDMA(3) + W43_NDMA(4), W43_LSET(1));
+                    else if (st == 8) W43_WAITN(4 + W43_NDMA(6) + W43_NDMA(7), W43_LSET(2)); else W43_WAITN(4 + W43_NDMA(9) + W43_NDMA(10), W43_LSET(3));
+                } else if (kind == 3) {
                     MICA_BLOAD43_L(4, wcur);
                     MICA_BLOAD43_H(0, wnxt);
-                    W43_WAIT(8, W43_HSET(4));
-                } else {
-                    W43_WAIT(4, W43_LSET(4));
+                    W43_WAITN(8 + W43_NDMA(9) + W43_NDMA(10) + W43_NDMA(11), W43_HSET(4));
+                } else if (kind == 4) {
+                    W43_WAITN(4 + W43_NDMA(12), W43_LSET(4));
                 }
-                static_assert(G::DPW <= 6, "DMAs are issued in the steps a0 .. bc2; the wait immediates above assume that");
+                static_assert(W43_NDMA(13) == 0, "no slab DMA in the last step: the chunk-end wait leaves exactly the next chunk's first H in flight");
                 __builtin_amdgcn_sched_barrier(0);
+                if (W43_SOFT && st == W43_DMA_FIRST) soft_wait(1, 12u * (unsigned)gch);      // every wave is done reading the buffer the DMAs overwrite
 #pragma unroll
-                for (int q = 0; q < W43_NDMA(st); ++q) MICA_SLAB_DMA43(nsrc, nxt_off, st + q, org);
+                for (int q = 0; q < W43_NDMA(st); ++q) MICA_SLAB_DMA43(nsrc, nxt_off, W43_DMA0(st) + q, org);
+                if (W43_SOFT && st == W43_LANDED_STEP) soft_signal(0);                                      // this wave's DMAs of the chunk have landed (see above)
                 const char* ab_nxt = ab_cur;
                 if (st + 1 < NS) ab_nxt = W43_ABASE(st + 1);
-                half8 (&b1)[NCT] = bq[kind == 3 ? W43_LSET(4) : W43_HSET(ps)];
-                half8 (&b2)[NCT] = bq[W43_LSET(ps)];
+                half8 (&b1)[NCT] = bq[(kind == 2 || kind == 4) ? W43_LSET(ps) : W43_HSET(ps)];
+#ifdef MICA43_PRIO
+                {   // experiments: priorities of the three waves that share a SIMD (wave, wave + 4, wave + 8)
+                    const int g3 = wave >> 2;
+                    const int pr = MICA43_PRIO == 1 ? (g3 + st) % 3 : MICA43_PRIO == 2 ? (g3 + st / 5) % 3 : MICA43_PRIO == 3 ? 2 - g3 : (g3 + st / 2) % 3;
+                    if (MICA43_PRIO != 3 || st == 0) {
+                        if (pr == 0) asm volatile("s_setprio 0"); else if (pr == 1) asm volatile("s_setprio 1"); else asm volatile("s_setprio 2");
+                    }
+                }
+#endif
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
                     const int fi = st * NF + f;                 // fragment index within the chunk; lives in ar[fi % (AD + 1)]
@@ -310,11 +375,6 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #pragma unroll
                     for (int c = 0; c < NCT; ++c)
                         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(ar[fi % (AD + 1)]), "v"(b1[c]));
-                    if (kind == 1) {
-#pragma unroll
-                        for (int c = 0; c < NCT; ++c)
-                            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(ar[fi % (AD + 1)]), "v"(b2[c]));
-                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 ab_cur = ab_nxt;
@@ -322,11 +382,23 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #undef W43_ABASE
 #undef W43_AFRAG
             // the slab DMAs of this chunk are older than the four weight loads (the next chunk's first H) still wanted in flight
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __syncthreads();
+            if (W43_SOFT && !last) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads of the chunk have returned
+                soft_signal(1);
+                soft_wait(0, 12u * (unsigned)(gch + 1));                // every wave's DMAs for the next chunk have landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                __syncthreads();
+                // every wave is past the item's chunks: restart the counters (the epilogue's barriers publish it before the next item)
+                if (W43_SOFT && tid == 0) { sync_ctr[0] = 0; sync_ctr[1] = 0; }
+                if (W43_SOFT && MICA43_EPI_PASSES == 0) __syncthreads();
+            }
             par ^= 1;
             wcur = wnxt;
         }
+#ifdef MICA43_PRIO
+        asm volatile("s_setprio 0");
+#endif
         // the next item's first weight fragments were requested two steps ago: retire them here (the compiler cannot see them in flight)
         W43_WAIT(0, W43_HSET(0));
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU/LDS readers
@@ -381,9 +453,9 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                     for (int c = 0; c < 4; ++c) {
                         const float s12 = a1[c] + a2[c], d12 = a1[c] - a2[c], s34 = a3[c] + a4[c], d34 = a3[c] - a4[c];
                         yv[0][c] = (a0[c] + s12 + s34) * out_scale + bb[c];
-                        yv[1][c] = (d12 + 2.f * d34) * out_scale + bb[c];
-                        yv[2][c] = (s12 + 4.f * s34) * out_scale + bb[c];
-                        yv[3][c] = (d12 + 8.f * d34 + a5[c]) * out_scale + bb[c];
+                        yv[1][c] = fmaf(W43_A, d12, W43_B * d34) * out_scale + bb[c];
+                        yv[2][c] = fmaf(W43_A2, s12, W43_B2 * s34) * out_scale + bb[c];
+                        yv[3][c] = (fmaf(W43_A3, d12, W43_B3 * d34) + a5[c]) * out_scale + bb[c];
                     }
                     const int gx = (tx * G::QX + (frow & (G::QX - 1))) * 4, gy = ty * G::TY + frow / G::QX, gz = tz * G::TZ + fz;
                     // statistics: sums of (v - shift), (v - shift)^2 with one shift per channel for the whole wave (the tile's first voxel)
@@ -454,6 +526,11 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #undef MICA_BLOAD43_L
 #undef W43_WAIT
 #undef W43_NDMA
+#undef W43_DMA0
+#undef W43_DMA_FIRST
+#undef W43_LANDED_STEP
+#undef W43_SOFT
+#undef W43_WAITN
 #undef W43_PS
 #undef W43_KIND
 #undef W43_HSET
@@ -473,7 +550,7 @@ int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstri
     for (int i = 0; i < s.n; ++i) total += s.chunks[i];
     const int ntx = (d.W + 4 * Geo43::QX - 1) / (4 * Geo43::QX), nty = (d.H + Geo43::TY - 1) / Geo43::TY, ntz = (d.D + Geo43::TZ - 1) / Geo43::TZ,
               nnb = cout / 128;
-    const size_t lds = 2 * Geo43::CH_BYTES;
+    const size_t lds = 2 * Geo43::CH_BYTES + 16;          // two slab buffers + the soft-synchronisation counters
     static unsigned long long seen = 0;
     static int cus_of[64] = {0};
     int dev = 0;
@@ -533,13 +610,15 @@ __global__ void pack_weights_wino43_kernel(const float* __restrict__ w, int cout
         if (ci >= 0 && tap < 9) {
             const float* g = w + ((int64_t)n * cin + ci) * 27 + tap * 3;
             const double g0 = g[0], g1 = g[1], g2 = g[2];
+            // G rows [1, p, p^2] / N_p, N_p = prod over the other finite points (p - p'); a = 3/2, b = 2/3, a b = 1
+            const double a = 1.5, b = 2.0 / 3.0, na = 2.0 * a * a * (a * a - b * b), nb = 2.0 * b * b * (b * b - a * a);
             double uu;
             switch (pp) {
-                case 0: uu = g0 / 4.0; break;
-                case 1: uu = -(g0 + g1 + g2) / 6.0; break;
-                case 2: uu = -(g0 - g1 + g2) / 6.0; break;
-                case 3: uu = g0 / 24.0 + g1 / 12.0 + g2 / 6.0; break;
-                case 4: uu = g0 / 24.0 - g1 / 12.0 + g2 / 6.0; break;
+                case 0: uu = g0; break;
+                case 1: uu = (g0 + a * g1 + a * a * g2) / na; break;
+                case 2: uu = (g0 - a * g1 + a * a * g2) / na; break;
+                case 3: uu = (g0 + b * g1 + b * b * g2) / nb; break;
+                case 4: uu = (g0 - b * g1 + b * b * g2) / nb; break;
                 default: uu = g2; break;
             }
             v = (float)uu * mul;
@@ -575,21 +654,6 @@ void launch_pack_weights_wino43(const float* w, int cout, int cin, const int* h_
 // output quad in wino43 layout.  Thread = (8-channel group, quad).  enc.ascale is the scale of the OPERAND (the callers pass a
 // quarter of the context's activation scale, see the header).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wino43_input_transform(const float (&dv)[6][8], float (&t)[6][8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float d0 = dv[0][j], d1 = dv[1][j], d2 = dv[2][j], d3 = dv[3][j], d4 = dv[4][j], d5 = dv[5][j];
-        t[0][j] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
-        const float e = fmaf(-4.f, d2, d4), o = fmaf(-4.f, d1, d3);      // t1 = e + o ; t2 = e - o
-        t[1][j] = e + o;
-        t[2][j] = e - o;
-        const float e2 = d4 - d2, o2 = 2.f * (d3 - d1);                   // t3 = e2 + o2 ; t4 = e2 - o2
-        t[3][j] = e2 + o2;
-        t[4][j] = e2 - o2;
-        t[5][j] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
-    }
-}
-
 __global__ __launch_bounds__(256) void prep_wino43_kernel(const float* __restrict__ x, Dims d, int C, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, int relu, SplitView wino, SplitEnc enc) {
     const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;

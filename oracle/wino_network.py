@@ -22,6 +22,7 @@ Variants of the 3^3 convs:
     f43@big    F(4,3) on encoder.2's conv3 (512->256) and transition (256->512) only - 51 % of the network's FLOPs
     f43h@big   the same with the +-1/2 points
     f43@e2     F(4,3) on all four 3^3 convs of encoder.2 (68 % of the FLOPs)
+    f43s, f43s@e2   the same with the points {0, +-3/2, +-2/3, inf} of the shipped kernel (kernels_conv43.hip)
 
 Criterion (tests/test_gpu_model.py): scaled error max |got - ref| / max(|ref|, rms(ref)) < 1e-4 against the reference module's
 float32 logits (tests/golden/model_S16_*.npz) AND against its float64 logits (truth64_S16_*.npz), the latter also <= 1.5x the
@@ -105,7 +106,9 @@ def _check_transform(T, m):
 F23 = cook_toom([0, 1, -1], 2)
 F43 = cook_toom([0, 1, -1, 2, -2], 4)
 F43H = cook_toom([0, 1, -1, 0.5, -0.5], 4)
-for _T, _m in ((F23, 2), (F43, 4), (F43H, 4)):
+from fractions import Fraction as _Fr                      # noqa: E402
+F43S = cook_toom([0, _Fr(3, 2), _Fr(-3, 2), _Fr(2, 3), _Fr(-2, 3)], 4)      # the shipped kernel's points (a b = 1: balanced products)
+for _T, _m in ((F23, 2), (F43, 4), (F43H, 4), (F43S, 4)):
     _check_transform(_T, _m)
 
 
@@ -192,7 +195,7 @@ class Emulated:
     def pick(self, cin, cout, name=""):
         v = self.variant
         if "@e2" in v:                                    # all four 3^3 convs of encoder.2 (conv1, conv2, conv3, transition)
-            return {"f43": F43, "f43h": F43H}[v.split("@")[0]] if name.startswith("encoder.2.") else F23
+            return {"f43": F43, "f43h": F43H, "f43s": F43S}[v.split("@")[0]] if name.startswith("encoder.2.") else F23
         if "@e2c" in v:
             pass
         if v == "direct":
@@ -201,7 +204,7 @@ class Emulated:
             return {"f43": F43, "f43h": F43H}[v.split("@")[0]] if cout >= 128 else F23
         if "@big" in v:                                   # encoder.2's conv3 (512->256) and transition (256->512): 51 % of the FLOPs
             return {"f43": F43, "f43h": F43H}[v.split("@")[0]] if cin * cout >= 512 * 256 else F23
-        return {"f23": F23, "f43": F43, "f43h": F43H}[v]
+        return {"f23": F23, "f43": F43, "f43h": F43H, "f43s": F43S}[v]
 
     def __enter__(self):
         self._conv, self._in = mo._conv, mo._in_relu
