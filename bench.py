@@ -30,7 +30,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what
 FLOPS_PER_TILE_AF = 7.3625e12       # BASELINE.md section 3 (AF path), measured on the reference model
 PEAK_F16_MFMA_TF = 2500.0           # MI355X dense f16 MFMA (MI355X_MICROARCH.md)
 PEAK_SPLIT_TF = PEAK_F16_MFMA_TF / 3.0   # this path spends three f16 MFMAs per f32-grade product
-WINO_MFMA_PER_ALGORITHMIC = 3.0 * (14.0 / 13.5) / 1.5      # executed f16 MFMA flops per algorithmic flop of a 3^3 conv
+WINO_MFMA_PER_ALGORITHMIC = 3.0 * (14.0 / 13.5) / 1.5      # executed f16 MFMA flops per algorithmic flop of a 3^3 conv, F(2,3)-x kernel
+WINO43_MFMA_PER_ALGORITHMIC = 3.0 * (14.0 / 13.5) / 2.0    # ... of the F(4,3)-x kernel (6 positions per 4 outputs: 13.5 MFMA-taps per output)
 
 
 def host_threads():
@@ -325,6 +326,7 @@ def main():
         ms, launches, flops = eng.profile(0)
         dms, dl, dbytes = eng.profile(1)
         wms, wl, wflops = eng.profile(2)
+        eng43 = eng.profile(5)
         eng.set_profiling(False)
         traffic, tp = {}, None
         import glob
@@ -335,23 +337,42 @@ def main():
         tpn = os.path.basename(tp) if tp else "none"
         ach_all = flops / (ms * 1e-3) / 1e12
         wach = wflops / (wms * 1e-3) / 1e12 if wms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "conv_wino16_kernel: every dense 3x3x3 conv via Winograd F(2,3)-x, split-f16 x3 MFMA (v_mfma_f32_16x16x32_f16)",
-                "achieved": wach, "peak": PEAK_SPLIT_TF, "unit": "TFLOP/s", "frac": wach / PEAK_SPLIT_TF,
-                "traffic": traffic.get("conv_wino16_kernel", {}).get("hbm_bytes"),
-                "launches_per_batch": wl, "avg_launch_ms": wms / max(wl, 1),
-                "algorithmic_gflop_per_launch_avg": wflops / max(wl, 1) / 1e9,
-                "executed_mfma": {"achieved": wach * WINO_MFMA_PER_ALGORITHMIC, "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s (f16 MFMA issued)",
-                                  "frac": wach * WINO_MFMA_PER_ALGORITHMIC / PEAK_F16_MFMA_TF,
-                                  "note": "algorithmic FLOPs / 1.5 (Winograd) x 3 (split products) x 14/13.5 (tap pairing) = f16 MFMA FLOPs the "
-                                          "kernel issues, over the 2.5 PF dense f16 peak: the hardware fraction"},
+        fms, fl, fflops = eng43
+        fach = fflops / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
+        # executed f16 MFMA FLOPs of all 3^3 launches together over their time: the hardware fraction of the conv kernels
+        ex_all = (wflops * WINO_MFMA_PER_ALGORITHMIC + fflops * WINO43_MFMA_PER_ALGORITHMIC) / max((wms + fms) * 1e-3, 1e-12) / 1e12
+        w16 = {"kernel": "conv_wino16_kernel<128|64|32>: Winograd F(2,3)-x, the 3x3x3 convs outside encoder.2", "achieved": wach,
+               "frac": wach / PEAK_SPLIT_TF, "launches_per_batch": wl, "avg_launch_ms": wms / max(wl, 1),
+               "executed_mfma_frac": wach * WINO_MFMA_PER_ALGORITHMIC / PEAK_F16_MFMA_TF,
+               "traffic": traffic.get("conv_wino16_kernel", {}).get("hbm_bytes")}
+        if fl > 0:
+            dom_name = ("conv_wino43_kernel: the four 3x3x3 convs of encoder.2 (68 % of the network's FLOPs) via Winograd F(4,3)-x, split-f16 x3 MFMA "
+                        "(v_mfma_f32_16x16x32_f16)")
+            dach_, dms_, dl_, dfl_, dfac, dkey = fach, fms, fl, fflops, WINO43_MFMA_PER_ALGORITHMIC, "conv_wino43_kernel"
+        else:
+            dom_name = "conv_wino16_kernel: every dense 3x3x3 conv via Winograd F(2,3)-x, split-f16 x3 MFMA (v_mfma_f32_16x16x32_f16)"
+            dach_, dms_, dl_, dfl_, dfac, dkey = wach, wms, wl, wflops, WINO_MFMA_PER_ALGORITHMIC, "conv_wino16_kernel"
+        roof = {"bound": "mfma", "kernel": dom_name,
+                "achieved": dach_, "peak": PEAK_SPLIT_TF, "unit": "TFLOP/s", "frac": dach_ / PEAK_SPLIT_TF,
+                "traffic": traffic.get(dkey, {}).get("hbm_bytes"),
+                "launches_per_batch": dl_, "avg_launch_ms": dms_ / max(dl_, 1),
+                "algorithmic_gflop_per_launch_avg": dfl_ / max(dl_, 1) / 1e9,
+                "executed_mfma": {"achieved": dach_ * dfac, "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s (f16 MFMA issued)",
+                                  "frac": dach_ * dfac / PEAK_F16_MFMA_TF,
+                                  "note": "algorithmic FLOPs / 2 (Winograd F(4,3): 13.5 instead of 27 MFMA-taps per output; / 1.5 for the F(2,3) kernel) x 3 "
+                                          "(split products) x 14/13.5 (tap pairing) = f16 MFMA FLOPs the kernel issues, over the 2.5 PF dense f16 peak: "
+                                          "the hardware fraction"},
+                "conv_wino16": w16,
+                "all_3x3x3_convs": {"launches_per_batch": wl + fl, "ms_per_batch": wms + fms,
+                                    "achieved": (wflops + fflops) / max((wms + fms) * 1e-3, 1e-12) / 1e12,
+                                    "executed_mfma_frac": ex_all / PEAK_F16_MFMA_TF},
                 "all_dense_convs": {"achieved": ach_all, "frac": ach_all / PEAK_SPLIT_TF, "launches_per_batch": launches,
                                     "note": "3x3x3 and 1x1x1 launches together (the 1x1 kernel is HBM-bound and also does the operand passes)"},
-                "note": "achieved = algorithmic direct-conv FLOPs (2*27*Cin*Cout*V, unpadded) of the conv_wino16_kernel launches of one batch / their "
-                        "HIP-event time (avg_launch_ms = the mean over its 22 launches: compare the kernel-trace summary under profiles/ for this round, "
-                        "three template variants); peak = f16 dense MFMA 2500 TF / 3 MFMAs per f32-grade product (833 TF); Winograd executes "
-                        "1.5x fewer MFMAs than the algorithmic count, so `frac` is an algorithmic rate and `executed_mfma` the hardware fraction; "
-                        "traffic = PMC HBM bytes per conv_wino16 launch at batch 8 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 "
-                        "corrections, profiles/" + tpn + "); null for other batch sizes"}
+                "note": "achieved = algorithmic direct-conv FLOPs (2*27*Cin*Cout*V, unpadded) of the dominant kernel's launches of one batch / their "
+                        "HIP-event time on the launch stream (avg_launch_ms: compare the kernel-trace summary under profiles/ for this round); peak = f16 "
+                        "dense MFMA 2500 TF / 3 MFMAs per f32-grade product (833 TF); Winograd executes fewer MFMAs than the algorithmic count, so `frac` "
+                        "is an algorithmic rate (it may exceed 1) and `executed_mfma` the hardware fraction; traffic = PMC HBM bytes per launch at batch 8 "
+                        "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections, profiles/" + tpn + "); null for other batch sizes"}
         dach = dbytes / (dms * 1e-3) / 1e9
         hbm = {"bound": "hbm", "kernel": "depthwise_kernel (Conv3d groups=C, 3x3x3, IN+ReLU+SE gate fused on load, IN stats fused)",
                "achieved": dach, "peak": 8000.0, "unit": "GB/s", "frac": dach / 8000.0,
