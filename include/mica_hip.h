@@ -232,6 +232,7 @@ int mica_op_stem(mica_ctx* ctx, const float* d_map, int batch, int d, int h, int
  * The setter takes a power of two in [2^-8, 16] as the scale every call starts from (tests; un-normalised inputs).     */
 float mica_get_activation_scale(const mica_ctx* ctx);
 float mica_get_last_forward_scale(const mica_ctx* ctx);
+int mica_get_last_forward_retries(const mica_ctx* ctx);     /* tiles of the last mica_forward_* call that were repeated at a lower scale */
 int mica_set_activation_scale(mica_ctx* ctx, float scale);
 
 /* ---- introspection for bench.py ----------------------------------------------------------- */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mica_op_stem": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "mica_get_activation_scale": (_F, [_P]),
     "mica_get_last_forward_scale": (_F, [_P]),
+    "mica_get_last_forward_retries": (_I, [_P]),
     "mica_set_activation_scale": (_I, [_P, _F]),
     "mica_set_profiling": (_I, [_P, _I]),
     "mica_get_conv_profile": (_I, [_P, _DP, _LP, _DP]),

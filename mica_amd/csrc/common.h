@@ -22,7 +22,7 @@ constexpr float ASCALE_MIN = 1.0f / 256.0f;
 constexpr float F16_LIMIT = 60000.0f;    // |x*ascale| above this sets the range flag
 constexpr int RANGE_OVERFLOW = 1, RANGE_NONFINITE = 2;      // bits of the range flag
 struct SplitEnc {           // where the split encoders report and how they scale
-    int* err;               // device flag, OR of RANGE_* bits
+    int* err;               // device flags int[batch of the launch], one per tile: OR of RANGE_* bits
     float ascale;
 };
 

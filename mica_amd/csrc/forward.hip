@@ -92,10 +92,12 @@ struct mica_ctx {
     float* ws = nullptr;          // reduction partials
     float* ws_gap = nullptr;      // depthwise: per-block sums of its normalised input [B][blocks][C]
     float *v_mean, *v_rstd, *v_mean3, *v_rstd3, *v_pool, *v_gse, *v_gate, *v_abs;
-    int* d_err = nullptr;
+    int* d_err = nullptr;            // range flags, one per tile of the call (int[maxB])
+    int* cur_err = nullptr;          // ... of the run of tiles forward_run is working on
     float ascale = ASCALE_DEFAULT;   // activation scale of the split encoding (common.h) every forward call starts from
     int f43_mode = 1;                // 0: every 3^3 conv on the F(2,3) kernel; 1: encoder.2's four convs on the F(4,3) kernel (default)
     float last_scale = ASCALE_DEFAULT;   // the lowest scale a tile of the last forward call needed (forward_checked)
+    int last_retries = 0;                // tiles of the last forward call that had to be repeated at a lower scale
     std::vector<char> use_af;        // per tile of the last forward_impl call: AF3 branch taken
     float* h_abs = nullptr;       // pinned
     int* h_err = nullptr;         // pinned
@@ -296,7 +298,7 @@ void run_conv1x1(mica_ctx* c, ConvLayer& L, Conv1Src a, const Conv1Src* b2, Spli
     const bool fused = conv1x1_can_emit_wino(c->d, f43 ? 2 : 1);
     prof_begin(c, 4, st);
     launch_conv1x1(src, L.d_wpk, L.per_tile ? L.pk_halves : 0, L.d_b, 1.0f / (L.wscale * c->ascale), fused ? nullptr : tmp_raw,
-                   fused ? dst : SplitView{nullptr, 0, 0, 0}, B, c->d, L.cout, SplitEnc{c->d_err, c->ascale}, st, f43 ? 2 : 1,
+                   fused ? dst : SplitView{nullptr, 0, 0, 0}, B, c->d, L.cout, SplitEnc{c->cur_err, c->ascale}, st, f43 ? 2 : 1,
                    f43 ? c->ascale / WINO43_ASCALE_DIV : c->ascale);
     prof_end(c, 4, L.flops_per_voxel * (double)c->V * B, st);
     if (!fused) make_operand(c, tmp_raw, B, L.cout, nullptr, nullptr, 0, dst, SplitView{nullptr, 0, 0, 0}, nullptr, st, f43);
@@ -317,30 +319,31 @@ void make_operand(mica_ctx* c, const float* raw, int B, int C, const float* mean
     struct End { mica_ctx* c; double b; hipStream_t s; ~End() { prof_end(c, 3, b, s); } } end_{c, bytes, st};
     if (t3.p && f43) {
         // F(4,3) operand of encoder.2's convs: no plain / pooled side outputs are ever wanted there
-        launch_prep_wino43(raw, B, c->d, C, mean, rstd, relu, t3, SplitEnc{c->d_err, c->ascale / WINO43_ASCALE_DIV}, st);
+        launch_prep_wino43(raw, B, c->d, C, mean, rstd, relu, t3, SplitEnc{c->cur_err, c->ascale / WINO43_ASCALE_DIV}, st);
     } else if (t3.p) {
-        launch_prep_wino(raw, B, c->d, C, mean, rstd, relu, nullptr, t3, t1, gap, c->ws, SplitEnc{c->d_err, c->ascale}, st);
+        launch_prep_wino(raw, B, c->d, C, mean, rstd, relu, nullptr, t3, t1, gap, c->ws, SplitEnc{c->cur_err, c->ascale}, st);
     } else {
-        launch_prep(raw, B, c->V, C, mean, rstd, relu, nullptr, t1, nullptr, gap, c->ws, SplitEnc{c->d_err, c->ascale}, st);
+        launch_prep(raw, B, c->V, C, mean, rstd, relu, nullptr, t1, nullptr, gap, c->ws, SplitEnc{c->cur_err, c->ascale}, st);
     }
 }
 
 // One run of tiles that share the AF branch (model.py:56-74).  Workspace slots 0..B-1.
 int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool use_af, float* o_bb, float* o_ca,
-                float* o_aa, hipStream_t st) {
+                float* o_aa, hipStream_t st, int slot0) {
     const int V = c->V;
     const Dims d = c->d;
     SplitView none{nullptr, 0, 0, 0};
+    c->cur_err = c->d_err + slot0;
     // ---- MultiScaleInput (model.py:43-74) ------------------------------------------------------
-    launch_stem(d_map, B, d, c->stem_w, c->stem_b, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, c->ws, SplitEnc{c->d_err, c->ascale}, st);
+    launch_stem(d_map, B, d, c->stem_w, c->stem_b, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, c->ws, SplitEnc{c->cur_err, c->ascale}, st);
     if (!use_af) {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->downsizing.d_cin_scale, 128, st);
         run_conv1x1(c, c->downsizing, split_src(c->S_exp, 8, 0, 8), nullptr, view(c->S_x0, 4, 0, 4), c->R_a, B, st);
     } else {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->fusion0.d_cin_scale, 192, st);
-        launch_prep_ncdhw_wino(d_af, B, d, 24, view(c->S_af, 2, 0, 2), SplitEnc{c->d_err, c->ascale}, st);
+        launch_prep_ncdhw_wino(d_af, B, d, 24, view(c->S_af, 2, 0, 2), SplitEnc{c->cur_err, c->ascale}, st);
         run_conv(c, c->feat_conv, SrcList().add(c->S_af, 2, 0, 2), c->R_b, B, st);
-        launch_feat_gate(c->R_b, B, V, c->fg_w0, c->fg_b0, c->fg_w2, c->fg_b2, view(c->S_fw, 4, 0, 4), SplitEnc{c->d_err, c->ascale}, st);
+        launch_feat_gate(c->R_b, B, V, c->fg_w0, c->fg_b0, c->fg_w2, c->fg_b2, view(c->S_fw, 4, 0, 4), SplitEnc{c->cur_err, c->ascale}, st);
         const Conv1Src fw = split_src(c->S_fw, 4, 0, 4);
         run_conv1x1(c, c->fusion0, split_src(c->S_exp, 8, 0, 8), &fw, view(c->S_x0, 4, 0, 4), c->R_a, B, st);
     }
@@ -402,12 +405,12 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         run_conv(c, H.conv1, src, c->R_a, B, st, c->v_mean, c->v_rstd);
         make_operand(c, c->R_a, B, 64, c->v_mean, c->v_rstd, 1, view(c->S_h1, 4, 0, 4), none, nullptr, st);
         run_conv(c, H.conv2, SrcList().add(c->S_h1, 4, 0, 4), c->R_b, B, st, c->v_mean, c->v_rstd);
-        launch_prep(c->R_b, B, V, 32, c->v_mean, c->v_rstd, 1, nullptr, none, nullptr, c->v_pool, c->ws, SplitEnc{c->d_err, c->ascale}, st);
+        launch_prep(c->R_b, B, V, 32, c->v_mean, c->v_rstd, 1, nullptr, none, nullptr, c->v_pool, c->ws, SplitEnc{c->cur_err, c->ascale}, st);
         gate(c, H.cal, c->v_pool, nullptr, B, nullptr, c->v_gate, nullptr, 0, st);
         const bool feeds = h < 2;
         launch_head_final(c->R_b, B, V, c->v_mean, c->v_rstd, c->v_gate, H.wf, H.bf, H.ncls, outs[h], 4 * h,
                           feeds ? c->extra_raw : nullptr, 8, st);
-        if (feeds) launch_prep_ncdhw_wino(c->extra_raw, B, d, 8, view(c->S_extra, 1, 0, 1), SplitEnc{c->d_err, c->ascale}, st);
+        if (feeds) launch_prep_ncdhw_wino(c->extra_raw, B, d, 8, view(c->S_extra, 1, 0, 1), SplitEnc{c->cur_err, c->ascale}, st);
     }
     return MICA_OK;
 }
@@ -422,7 +425,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     const int V = c->V;
     c->ev_used = 0;
     for (double& w : c->prof_work) w = 0;
-    HIPC(c, hipMemsetAsync(c->d_err, 0, sizeof(int), st));
+    HIPC(c, hipMemsetAsync(c->d_err, 0, sizeof(int) * B, st));
     std::vector<char> use(B, 0);
     if (force_use) {
         for (int b = 0; b < B; ++b) use[b] = force_use[b];
@@ -445,7 +448,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
         int b1 = b0 + 1;
         while (b1 < B && use[b1] == use[b0]) ++b1;
         int r = forward_run(c, d_map + (int64_t)b0 * V, d_af ? d_af + (int64_t)b0 * 24 * V : nullptr, b1 - b0, use[b0] != 0,
-                            o_bb + (int64_t)b0 * 4 * V, o_ca + (int64_t)b0 * 4 * V, o_aa + (int64_t)b0 * 21 * V, st);
+                            o_bb + (int64_t)b0 * 4 * V, o_ca + (int64_t)b0 * 4 * V, o_aa + (int64_t)b0 * 21 * V, st, b0);
         if (r) return r;
         b0 = b1;
     }
@@ -484,17 +487,16 @@ bool pow2_8_512(int c) { return c >= 8 && c <= 512 && (c & (c - 1)) == 0; }
 
 
 // The forward with the range check of the split-f16 encoding (synchronises `st`).  An activation beyond the f16 range at the
-// context's activation scale (|x| * ascale > 60000) is handled PER TILE and PER CALL: the tiles of the batch are repeated one
-// by one, each from the context's scale again, and only a tile that overflows alone steps down by 4 (exact: powers of two,
-// undone in the conv epilogues) until it fits.  A tile's numbers therefore never depend on its batch neighbours, on tiles or
+// context's activation scale (|x| * ascale > 60000) is handled PER TILE and PER CALL: every encoder raises the flag of the tile it
+// is working on (int[batch] on the device), and only the flagged tiles are repeated, alone, stepping down by 4 (exact: powers of
+// two, undone in the conv epilogues; never past the smallest scale without trying it) until they fit.  A tile's numbers therefore never depend on its batch neighbours, on tiles or
 // maps processed earlier, or on which rank of a sharded run met the outlier; the context's scale is not changed.  Below ~1 the
 // lo halves of O(1) activations go subnormal in f16 and the whole-network error grows (DESIGN.md section 2 has the measured
 // table); mica_get_last_forward_scale() reports the lowest scale the call used so that the caller can tell.  NaN/Inf, or an
 // overflow at the smallest scale, fail loudly with MICA_ERR_RANGE rather than return clipped numbers.
-static int range_flag(mica_ctx* c, hipStream_t st, int* flag) {
-    HIPC(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+static int range_flags(mica_ctx* c, hipStream_t st, int n) {        // -> c->h_err[0..n)
+    HIPC(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(int) * n, hipMemcpyDeviceToHost, st));
     HIPC(c, hipStreamSynchronize(st));
-    *flag = *c->h_err;
     return MICA_OK;
 }
 static int range_error(mica_ctx* c, int flag) {
@@ -506,24 +508,30 @@ static int forward_checked(mica_ctx* c, const float* d_map, const float* d_af, i
                            float* o_aa, hipStream_t st) {
     const float base = c->ascale;
     c->last_scale = base;
-    int flag = 0;
+    c->last_retries = 0;
     int r = forward_impl(c, d_map, d_af, B, af_mode, o_bb, o_ca, o_aa, st);
-    if (r || (r = range_flag(c, st, &flag))) return r;
-    if (!flag) return MICA_OK;
-    if (flag & RANGE_NONFINITE) return range_error(c, flag);
+    if (r || (r = range_flags(c, st, B))) return r;
+    std::vector<int> flags(c->h_err, c->h_err + B);      // one per tile: every encoder reports under the tile it is working on
+    int any = 0;
+    for (int f : flags) any |= f;
+    if (!any) return MICA_OK;
+    if (any & RANGE_NONFINITE) return range_error(c, any);
     const std::vector<char> use = c->use_af;          // the gate decisions of the whole call (MICA_AF_BATCH looks at all tiles)
     const int V = c->V;
     for (int b = 0; b < B && !r; ++b) {
-        // a single tile that overflowed at `base` has nothing new to learn there
-        c->ascale = (B == 1) ? base * 0.25f : base;
+        if (!flags[b]) continue;                      // this tile fitted: its numbers stand (they do not depend on its batch neighbours)
+        ++c->last_retries;
+        if (base <= ASCALE_MIN) { r = range_error(c, RANGE_OVERFLOW); break; }
+        c->ascale = std::max(base * 0.25f, ASCALE_MIN);
         for (;;) {
-            if (c->ascale < ASCALE_MIN) { r = range_error(c, RANGE_OVERFLOW); break; }
             r = forward_impl(c, d_map + (int64_t)b * V, d_af ? d_af + (int64_t)b * 24 * V : nullptr, 1, af_mode, o_bb + (int64_t)b * 4 * V,
                              o_ca + (int64_t)b * 4 * V, o_aa + (int64_t)b * 21 * V, st, &use[b]);
-            if (r || (r = range_flag(c, st, &flag))) break;
+            if (r || (r = range_flags(c, st, 1))) break;
+            const int flag = c->h_err[0];
             if (!flag) { c->last_scale = std::min(c->last_scale, c->ascale); break; }
             if (flag & RANGE_NONFINITE) { r = range_error(c, flag); break; }
-            c->ascale *= 0.25f;
+            if (c->ascale <= ASCALE_MIN) { r = range_error(c, RANGE_OVERFLOW); break; }
+            c->ascale = std::max(c->ascale * 0.25f, ASCALE_MIN);      // never steps past the smallest scale without trying it
         }
     }
     c->ascale = base;
@@ -586,9 +594,9 @@ int mica_create(int device, int max_batch, int tile_size, mica_ctx** out) {
     if (!r) r = dalloc(c, &c->ws_gap, (int64_t)max_batch * ((tile_size + 15) / 16) * ((tile_size + 7) / 8) * 256);
     auto Vv = [&](float** p) { if (!r) r = dalloc(c, p, (int64_t)max_batch * 512); };
     Vv(&c->v_mean); Vv(&c->v_rstd); Vv(&c->v_mean3); Vv(&c->v_rstd3); Vv(&c->v_pool); Vv(&c->v_gse); Vv(&c->v_gate); Vv(&c->v_abs);
-    if (!r) r = dalloc(c, &c->d_err, 4);
+    if (!r) r = dalloc(c, &c->d_err, max_batch);
     if (!r && hipHostMalloc((void**)&c->h_abs, sizeof(float) * max_batch) != hipSuccess) { c->err = "hipHostMalloc failed"; r = MICA_ERR_HIP; }
-    if (!r && hipHostMalloc((void**)&c->h_err, sizeof(int)) != hipSuccess) { c->err = "hipHostMalloc failed"; r = MICA_ERR_HIP; }
+    if (!r && hipHostMalloc((void**)&c->h_err, sizeof(int) * max_batch) != hipSuccess) { c->err = "hipHostMalloc failed"; r = MICA_ERR_HIP; }
     if (r) {
         g_create_err = "mica_create: " + c->err;
         mica_destroy(c);
@@ -1005,13 +1013,13 @@ int mica_op_conv3d_variant(mica_ctx* c, const float* d_x, int batch, int cin, in
     float* raw = t.get<float>((int64_t)batch * V * cout);
     _Float16* pk = t.get<_Float16>(f43 ? packed_weight_halves_wino43(cout, cp / 16)
                                        : wino ? packed_weight_halves_wino(cout, cp / 16) : packed_weight_halves(cout, k, cp / 16));
-    int* derr = t.get<int>(1);
+    int* derr = t.get<int>(batch);
     if (!sx || !dw || !db || !raw || !pk || !derr) { c->err = "mica_op_conv3d: hipMalloc failed"; return MICA_ERR_HIP; }
     std::vector<float> hw(h_w, h_w + (size_t)cout * cin * nt);
     float ws = pick_wscale(hw, 1.f);
     HIPC(c, hipMemcpyAsync(dw, h_w, sizeof(float) * cout * cin * nt, hipMemcpyHostToDevice, st));
     HIPC(c, hipMemcpyAsync(db, h_b, sizeof(float) * cout, hipMemcpyHostToDevice, st));
-    HIPC(c, hipMemsetAsync(derr, 0, 4, st));
+    HIPC(c, hipMemsetAsync(derr, 0, sizeof(int) * batch, st));
     int sc[1] = {cin}, scp[1] = {cp};
     ConvSrcs s{};
     s.n = 1; s.p[0] = sx; s.chunks_total[0] = cp / 16; s.chunk_off[0] = 0; s.chunks[0] = cp / 16;
@@ -1072,7 +1080,7 @@ int mica_op_norm_conv1_conv3_variant(mica_ctx* c, const float* d_x, int batch, i
     float* db3 = t.get<float>(cout);
     _Float16* pk1 = t.get<_Float16>(packed_weight_halves(cmid, 1, cin / 16));
     _Float16* pk3 = t.get<_Float16>(f43 ? packed_weight_halves_wino43(cout, cmid / 16) : packed_weight_halves_wino(cout, cmid / 16));
-    int* derr = t.get<int>(1);
+    int* derr = t.get<int>(batch);
     if (!xr || !mean || !rstd || !ws || !mid || !op || !raw || !dw1 || !db1 || !dw3 || !db3 || !pk1 || !pk3 || !derr) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
     std::vector<float> v1(h_w1, h_w1 + (size_t)cmid * cin), v3(h_w3, h_w3 + (size_t)cout * cmid * 27);
     const float s1 = pick_wscale(v1, 1.f), s3 = pick_wscale(v3, 1.f);
@@ -1080,7 +1088,7 @@ int mica_op_norm_conv1_conv3_variant(mica_ctx* c, const float* d_x, int batch, i
     HIPC(c, hipMemcpyAsync(db1, h_b1, sizeof(float) * cmid, hipMemcpyHostToDevice, st));
     HIPC(c, hipMemcpyAsync(dw3, h_w3, sizeof(float) * cout * cmid * 27, hipMemcpyHostToDevice, st));
     HIPC(c, hipMemcpyAsync(db3, h_b3, sizeof(float) * cout, hipMemcpyHostToDevice, st));
-    HIPC(c, hipMemsetAsync(derr, 0, 4, st));
+    HIPC(c, hipMemsetAsync(derr, 0, sizeof(int) * batch, st));
     const SplitEnc enc{derr, ASCALE_DEFAULT};
     launch_nchw_to_nhwc(d_x, batch, cin, V, xr, st);
     launch_stats(xr, batch, V, cin, 1e-5f, mean, rstd, ws, st);
@@ -1122,7 +1130,7 @@ int mica_op_instnorm_relu(mica_ctx* c, const float* d_x, int batch, int ch, int 
     float* mean = t.get<float>((int64_t)batch * ch);
     float* rstd = t.get<float>((int64_t)batch * ch);
     float* ws = t.get<float>(stats_ws_floats(batch, ch));
-    int* derr = t.get<int>(1);
+    int* derr = t.get<int>(batch);
     if (!a || !b || !mean || !rstd || !ws || !derr) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
     launch_stats(a, batch, V, ch, 1e-5f, mean, rstd, ws, st);
@@ -1187,7 +1195,7 @@ int mica_op_se_depthwise(mica_ctx* c, const float* d_x, int batch, int ch, int d
     const int64_t wsn = std::max(stats_ws_floats(batch, ch), (int64_t)batch * nblk * ch * 3);
     float* ws = t.get<float>(wsn);
     float* wsg = t.get<float>((int64_t)batch * nblk * ch);
-    int* derr = t.get<int>(1);
+    int* derr = t.get<int>(batch);
     if (!a || !u || !y || !dw || !db || !w1 || !b1 || !w2 || !b2 || !m0 || !r0 || !m1 || !r1 || !pool || !gse || !ws || !wsg || !derr) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
     std::vector<float> wt((size_t)27 * ch);
     for (int cc = 0; cc < ch; ++cc)
@@ -1198,7 +1206,7 @@ int mica_op_se_depthwise(mica_ctx* c, const float* d_x, int batch, int ch, int d
     HIPC(c, hipMemcpy(b1, h_fc0_b, sizeof(float) * Ch, hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(w2, h_fc3_w, sizeof(float) * ch * Ch, hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(b2, h_fc3_b, sizeof(float) * ch, hipMemcpyHostToDevice));
-    HIPC(c, hipMemsetAsync(derr, 0, 4, st));
+    HIPC(c, hipMemsetAsync(derr, 0, sizeof(int) * batch, st));
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
     launch_stats(a, batch, V, ch, 1e-5f, m0, r0, ws, st);                                  // x3 = relu(IN(x)) is applied on load
     const int P = launch_depthwise(a, batch, dm, ch, m0, r0, nullptr, dw, db, u, ws, wsg, st);
@@ -1230,6 +1238,8 @@ int mica_op_stem(mica_ctx* c, const float* d_map, int batch, int d, int h, int w
 }
 
 float mica_get_activation_scale(const mica_ctx* c) { return c ? c->ascale : 0.f; }
+int mica_get_last_forward_retries(const mica_ctx* c) { return c ? c->last_retries : 0; }
+
 float mica_get_last_forward_scale(const mica_ctx* c) { return c ? c->last_scale : 0.f; }
 
 int mica_set_activation_scale(mica_ctx* c, float scale) {

@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ map
             if ((tid & 63) == 0) csum[tid >> 6][c * 32 + co] = sv;
         }
     }
-    if (bad && enc.err) atomicOr(enc.err, bad);
+    if (bad && enc.err) atomicOr(enc.err + b, bad);
     __syncthreads();
     if (ws && tid < 128)
         ws[((int64_t)b * gridDim.x + blockIdx.x) * 128 + tid] = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
             commit(p + 1, smem + ((p + 1) & 1) * C1_STAGE);
         }
     }
-    if (bad) atomicOr(enc.err, bad);
+    if (bad) atomicOr(enc.err + b, bad);
 
     // ---- epilogue: 64 output channels per pass through the staging tile T[128][64 (+4)] ----
     float* T = reinterpret_cast<float*>(smem);
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
             }
         }
     }
-    if (bad2) atomicOr(enc.err, bad2);
+    if (bad2) atomicOr(enc.err + b, bad2);
 }
 
 

@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void prep_wino43_kernel(const float* __restric
             *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 2 + kh) * Vq + ph) * 8) = lo;
         }
     }
-    if (bad) atomicOr(enc.err, bad);
+    if (bad) atomicOr(enc.err + b, bad);
 }
 
 void launch_prep_wino43(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, int relu, SplitView wino,
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void prep_ncdhw_wino43_kernel(const float* __r
             *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 2 + kh) * Vq + ph) * 8) = lo;
         }
     }
-    if (bad) atomicOr(enc.err, bad);
+    if (bad) atomicOr(enc.err + b, bad);
 }
 
 void launch_prep_ncdhw_wino43(const float* x, int B, Dims d, int C, SplitView wino, SplitEnc enc, hipStream_t st) {

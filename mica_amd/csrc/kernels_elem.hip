@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ x, 
             *reinterpret_cast<half8*>(ob + (int64_t)v * 32 + 16) = lo;
         }
     }
-    if (bad) atomicOr(enc.err, bad);
+    if (bad) atomicOr(enc.err + b, bad);
     if (ws) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) sh[tid * 8 + j] = acc[j];
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void prep_wino_kernel(const float* __restrict_
                 }
         }
     }
-    if (bad) atomicOr(enc.err, bad);
+    if (bad) atomicOr(enc.err + b, bad);
     if (ws) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) sh[tid * 8 + j] = acc[j];
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void prep_ncdhw_wino_kernel(const float* __res
         *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 1) * Vh + ph) * 8) = hi;
         *reinterpret_cast<half8*>(wb + ((int64_t)(pp * 4 + 3) * Vh + ph) * 8) = lo;
     }
-    if (bad) atomicOr(enc.err, bad);
+    if (bad) atomicOr(enc.err + b, bad);
 }
 void launch_prep_ncdhw_wino(const float* x, int B, Dims d, int C, SplitView wino, SplitEnc enc, hipStream_t st) {
     int Vh = d.D * d.H * ((d.W + 1) / 2);
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void prep_ncdhw_kernel(const float* __restrict
             *reinterpret_cast<half8*>(o + 24) = lo;
         }
     }
-    if (bad) atomicOr(enc.err, bad);
+    if (bad) atomicOr(enc.err + b, bad);
     if (abs_sum) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) asum += __shfl_xor(asum, o);
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void feat_gate_kernel(const float* __restrict_
             *reinterpret_cast<half8*>(o + 16 + kh * 8) = lo;
         }
     }
-    if (bad) atomicOr(enc.err, bad);
+    if (bad) atomicOr(enc.err + b, bad);
 }
 void launch_feat_gate(const float* x, int B, int V, const float* w0, const float* b0, const float* w2, const float* b2,
                       SplitView out, SplitEnc enc, hipStream_t st) {

@@ -45,7 +45,7 @@ class Engine:
         self.conv_variant = int(self.lib.mica_get_conv_variant(self._h))
         self.weights_loaded = False
         self.last_forward_scale = 16.0     # lowest activation scale any chunk of the last forward_* call needed
-        self.forward_retries = 0           # chunks of the last forward_* call that had to repeat a tile at a lower scale
+        self.forward_retries = 0           # tiles of the last forward_* call that were repeated at a lower activation scale
 
     # -- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -94,8 +94,7 @@ class Engine:
     def _check_forward(self, r, what):
         self._check(r, what)
         sc = float(self.lib.mica_get_last_forward_scale(self._h))
-        if sc < float(self.lib.mica_get_activation_scale(self._h)):
-            self.forward_retries += 1
+        self.forward_retries += int(self.lib.mica_get_last_forward_retries(self._h))
         self.last_forward_scale = min(self.last_forward_scale, sc)
         if sc < self.LOW_SCALE_WARN:
             import warnings
