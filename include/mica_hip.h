@@ -13,7 +13,13 @@
  *   - every pointer named d_* is DEVICE memory owned by the caller (e.g. a torch tensor's
  *     data_ptr()); h_* is HOST memory.  `stream` is a hipStream_t passed as void* (NULL = default).
  *   - one mica_ctx per GPU; a ctx is not thread-safe, different ctxs are independent.
- *   - all calls are asynchronous on `stream` unless stated otherwise.
+ *   - kernels are launched on `stream`.  Which calls return before the device work is done is stated per function:
+ *       asynchronous (enqueue and return): mica_gather_tiles(_u8), mica_stitch_tiles, mica_postprocess;
+ *       SYNCHRONISE `stream` before returning: mica_forward_logits / _tiles / _records (they read back the per-tile |AF3| sums that
+ *       pick the branch of models/model.py:56-63 and the per-tile range flags of the split-f16 encoding, and may repeat a tile, see
+ *       mica_get_last_forward_scale), mica_finalize_weights, mica_normalise_map*, mica_zoom_cubic*, mica_rasterise_atoms, the point-list
+ *       functions and every mica_op_*.  A host pipeline that wants to overlap uploads with a forward does so from a second stream /
+ *       thread (mica_amd/predict.py, mica_amd/pipeline.py::predict_maps_streamed), not by relying on the forward returning early.
  *   - volumes are C-contiguous [N0][N1][N2] in the (x,y,z) index order the reference uses after
  *     GridCreator.transpose (create_grids.py:67-87); tiles are [W][W][W], W = grid + 2*pad.
  */
@@ -42,7 +48,10 @@ typedef struct mica_ctx mica_ctx;
 int mica_abi_version(void);
 
 /* ---- context ---------------------------------------------------------------------------- */
-/* Allocates the activation workspace for up to max_batch tiles of tile_size^3 voxels in flight. */
+/* Allocates the activation workspace for up to max_batch tiles of tile_size^3 voxels in flight (about 4.6 GB per 64^3 tile).
+ * Limits: 1 <= max_batch <= 64; tiles are CUBIC, 4 <= tile_size <= 128 (the reference's MICA.forward is size-agnostic and its
+ * predictor uses 64 = grid 48 + 2 x 8, utils/predict.py; non-cubic tiles are refused, not silently reshaped); the network is the
+ * reference's base_filters = 64 configuration (models/model.py:262-293), the only one its checkpoints have.                    */
 int mica_create(int device, int max_batch, int tile_size, mica_ctx** out);
 void mica_destroy(mica_ctx* ctx);
 const char* mica_last_error(const mica_ctx* ctx);   /* ctx may be NULL: last create() error */
@@ -52,8 +61,15 @@ int64_t mica_workspace_bytes(const mica_ctx* ctx);
 /* One call per state_dict tensor (125 of them, names without the "module." prefix, fp32,
  * torch layout: Conv3d [Cout][Cin/groups][kD][kH][kW], Linear [out][in], fpn.weights [3]).   */
 int mica_load_weight(mica_ctx* ctx, const char* name, const float* h_data, const int64_t* shape, int ndim);
-/* Checks that all 125 tensors are present with the right shapes, uploads and packs them into the
- * kernels' layouts (split-f16 [cin/16][tap][hi|lo][k-half][Cout][8]); blocks until done.      */
+/* Checks that all 125 tensors are present with the right shapes (a missing or mis-shaped tensor is an error: stricter than the
+ * reference's load_state_dict(strict=False), predict.py:240), uploads them and packs the conv weights into the kernels' layouts
+ * - f16 hi + lo halves of w * 2^k (k per layer: max |w| in (2048, 4096]):
+ *     1x1x1 convs                 [Cin/16][hi|lo][k-half][Cout][8]
+ *     3x3x3 convs, F(2,3) kernel  [Cout/bn][Cin/16][tap pair 5][Winograd position 4][unit 8][bn][8], bn = 128 / 64 / 32
+ *     3x3x3 convs, F(4,3) kernel  [Cout/128][Cin/16][tap pair 5][Winograd position 6][unit 8][128][8]   (encoder.2, see
+ *                                 mica_set_conv_variant); units = hi / lo x first / second tap of the pair x channel half
+ *   with the Winograd weight transforms applied (the layers whose inputs carry a per-tile gate are re-packed per tile at run time).
+ * Blocks until done.                                                                                                            */
 int mica_finalize_weights(mica_ctx* ctx);
 
 /* Which dense 3x3x3 convs run on the Winograd F(4,3)-along-x kernel (1.33x fewer MFMAs, ~4x the per-layer rounding error) instead
@@ -118,11 +134,23 @@ int mica_normalise_map(mica_ctx* ctx, float* d_vol, int64_t n, double* h_stats, 
  *   normalise - np.median of integers is float64 and `norm_data - median` (:124) promotes the whole computation to float64:
  *               float64 percentile interpolation, clip and division, one rounding to float32 at :139.
  * (mode 12, float16: scipy.ndimage refuses the dtype, so the reference reports failure and so does the caller here.)      */
+#ifndef MICA_NUMPY_NEP50
+#define MICA_NUMPY_NEP50 0      /* numpy >= 2 promotion rules (NEP 50) */
+#define MICA_NUMPY_LEGACY 1     /* numpy 1.x value-based casting */
+#endif
 #define MICA_MAP_F32 0
 #define MICA_MAP_I8 1
 #define MICA_MAP_I16 2
 #define MICA_MAP_U16 3
 int mica_normalise_map_typed(mica_ctx* ctx, float* d_vol, int64_t n, int map_type, double* h_stats, void* stream);
+/* The same with numpy's promotion rules named (MICA_NUMPY_NEP50 / MICA_NUMPY_LEGACY, defined with mica_neighbour_matrix_np below).
+ * Under numpy 1.x - the reference pins 1.19.1 (environment.yml:8) - np.percentile interpolates with float64 weights as
+ * x_below * w_below + x_above * w_above and returns a float64 for every input type; on a float32 map `(m >= p) * p` is then a
+ * float64 array, so the clip and the division (preprocessing.py:131-133) run in float64 with one rounding at astype(float32)
+ * (:139), while the comparisons use p rounded to float32.  numpy 2 (what mica_normalise_map_typed does, pinned by the reference
+ * run in this repo's build container) does all of it in float32.  The two differ in the last bit of some voxels.  No fixture of
+ * the reference covers the 1.x arithmetic: it is restated from numpy 1.19's source (oracle/volume_oracle.py) - parity unpinned. */
+int mica_normalise_map_np(mica_ctx* ctx, float* d_vol, int64_t n, int map_type, int numpy_rules, double* h_stats, void* stream);
 
 /* ---- resampler: scipy.ndimage.zoom(data, factors, order=3) as called at preprocessing.py:117 ---- */
 /* d_in f32[n0][n1][n2] -> d_out f32[o0][o1][o2], o = int(round(n * factor)) chosen by the caller exactly as scipy does
@@ -182,8 +210,10 @@ int mica_neighbour_matrix(mica_ctx* ctx, const double* d_cands, int64_t n, const
  * np.float32` is a float64 accumulation and the whole score stays float64).  The two differ by ~1e-7 relative, enough to flip
  * near-ties in the caller's neigh_mat.argsort()[-2:].  (The cluster sums of mica_segment_sums are np.sum over float32 arrays:
  * float32 under both rule sets.)                                                                                              */
+#ifndef MICA_NUMPY_NEP50
 #define MICA_NUMPY_NEP50 0
 #define MICA_NUMPY_LEGACY 1
+#endif
 int mica_neighbour_matrix_np(mica_ctx* ctx, const double* d_cands, int64_t n, const float* d_bb, int64_t n0, int64_t n1, int64_t n2,
                              int numpy_rules, double* d_dis, double* d_mat, void* stream);
 

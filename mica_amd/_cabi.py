@@ -39,6 +39,7 @@ SIGNATURES = {
     "mica_normalise_map": (_I, [_P, _P, _L, _DP, _P]),
     "mica_zoom_cubic": (_I, [_P, _P, _L, _L, _L, _L, _L, _L, _P, _P]),
     "mica_normalise_map_typed": (_I, [_P, _P, _L, _I, _DP, _P]),
+    "mica_normalise_map_np": (_I, [_P, _P, _L, _I, _I, _DP, _P]),
     "mica_zoom_cubic_typed": (_I, [_P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P]),
     "mica_rasterise_atoms": (_I, [_P, _P, _P, _P, _L, _FP, _L, _L, _L, _P, _P]),
     "mica_threshold_points": (_I, [_P, _P, _L, _F, _P, _L, _LP, _P]),

@@ -205,7 +205,7 @@ void launch_gather_tiles_u8(const uint8_t* vol, int C, int64_t n0, int64_t n1, i
 void launch_stitch_tiles(const float* tiles, int C, int64_t n0, int64_t n1, int64_t n2, int grid, int pad,
                          int64_t first, int64_t count, float* vol, hipStream_t st);
 // exact order statistics of a f32 array (radix select) ; see kernels_select.hip
-int normalise_map_device(float* d_vol, int64_t n, int kind, double* h_stats, hipStream_t st, char* err, int errlen);
+int normalise_map_device(float* d_vol, int64_t n, int kind, int numpy_rules, double* h_stats, hipStream_t st, char* err, int errlen);
 // scipy.ndimage.zoom(order=3) restated bit-exactly in f64 ; see kernels_zoom.hip (synchronous)
 int zoom_cubic_device(const float* d_in, int64_t n0, int64_t n1, int64_t n2, int64_t o0, int64_t o1, int64_t o2, int kind, float* d_out,
                       hipStream_t st, char* err, int errlen);

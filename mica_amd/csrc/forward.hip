@@ -846,14 +846,19 @@ int mica_stitch_tiles(mica_ctx* c, const float* d_tiles, int channels, int64_t n
 }
 
 int mica_normalise_map_typed(mica_ctx* c, float* d_vol, int64_t n, int map_type, double* h_stats, void* stream) {
+    return mica_normalise_map_np(c, d_vol, n, map_type, MICA_NUMPY_NEP50, h_stats, stream);
+}
+
+int mica_normalise_map_np(mica_ctx* c, float* d_vol, int64_t n, int map_type, int numpy_rules, double* h_stats, void* stream) {
     if (!c) return MICA_ERR_ARG;
-    if (!d_vol || n < 1 || !h_stats || map_type < MICA_MAP_F32 || map_type > MICA_MAP_U16) {
+    if (!d_vol || n < 1 || !h_stats || map_type < MICA_MAP_F32 || map_type > MICA_MAP_U16 ||
+        (numpy_rules != MICA_NUMPY_NEP50 && numpy_rules != MICA_NUMPY_LEGACY)) {
         c->err = "mica_normalise_map: bad argument";
         return MICA_ERR_ARG;
     }
     HIPC(c, hipSetDevice(c->device));
     char buf[256] = {0};
-    int r = normalise_map_device(d_vol, n, map_type, h_stats, (hipStream_t)stream, buf, sizeof(buf));
+    int r = normalise_map_device(d_vol, n, map_type, numpy_rules, h_stats, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
     return r;
 }

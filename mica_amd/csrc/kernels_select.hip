@@ -61,6 +61,19 @@ __global__ void finish_kernel(float* __restrict__ x, int64_t n, float med, float
     }
 }
 
+// numpy 1.x promotion rules on a float32 map (MICA_NUMPY_LEGACY; the reference pins numpy 1.19.1, environment.yml:8): np.percentile
+// returns a float64 there, `(map_data_ >= p) * p` (bool array times a float64 scalar) is a float64 array, so the sum, the division
+// (:131-133) and everything up to the final astype(float32) (:139) run in float64, while the two comparisons against p are
+// float32 loops with p rounded to float32 (same-kind scalar: the array's type wins).
+__global__ void finish_legacy_kernel(float* __restrict__ x, int64_t n, float med, float pcmp, double pct) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float m = (v > med) ? (v - med) : 0.f;
+        const double c = (m < pcmp) ? (double)m : pct;
+        x[i] = (float)(c / pct);
+    }
+}
+
 // Integer maps (MRC modes 0 / 1 / 6): numpy promotes them to float64 at `norm_data - median` (:124) and stays there until the
 // final astype(float32) (:139).  The map holds the integers as f32; differences against the median (an integer or a half) are
 // exact in either width, so only the clip / divide / final rounding need the wide type.
@@ -107,8 +120,21 @@ struct Sel {
 };
 }  // namespace
 
-int normalise_map_device(float* d_vol, int64_t n, int kind, double* h_stats, hipStream_t st, char* err, int errlen) {
+// numpy 1.19's 'linear' percentile (function_base.py, _quantile_ureduce_func): float64 virtual index and weights for every input
+// type, and the weighted sum x_below * w_below + x_above * w_above instead of numpy 2's _lerp
+static double percentile_weights_legacy(int64_t P, int64_t* below, int64_t* above, double* w_above) {
+    const double q = 99.9 / 100.0;
+    const double ind = q * (double)(P - 1);
+    *below = (int64_t)floor(ind);
+    *above = *below + 1;
+    if (*above > P - 1) *above = P - 1;
+    *w_above = ind - (double)*below;
+    return 1.0 - *w_above;
+}
+
+int normalise_map_device(float* d_vol, int64_t n, int kind, int numpy_rules, double* h_stats, hipStream_t st, char* err, int errlen) {
     const bool wide = kind != MICA_MAP_F32;
+    const bool legacy = numpy_rules == MICA_NUMPY_LEGACY;
     unsigned* d_hist = nullptr;
     if (hipMalloc((void**)&d_hist, 256 * sizeof(unsigned)) != hipSuccess) { snprintf(err, errlen, "normalise: hipMalloc failed"); return -2; }
     int rc = 0;
@@ -143,10 +169,34 @@ int normalise_map_device(float* d_vol, int64_t n, int kind, double* h_stats, hip
             const double dd = (double)hi - (double)lo;
             double pctd = (double)lo + dd * gd;
             if (gd >= 0.5) pctd = (double)hi - dd * (1.0 - gd);
+            if (legacy) {
+                int64_t ib, ia;
+                double wa;
+                const double wb = percentile_weights_legacy(P, &ib, &ia, &wa);
+                if (p.run(ib, &lo, nullptr) || p.run(ia, &hi, nullptr)) { rc = -2; break; }
+                const double x1 = (double)lo * wb;
+                const double x2 = (double)hi * wa;
+                pctd = x1 + x2;
+            }
             if (pctd == 0.0) { snprintf(err, errlen, "Percentile value is zero - cannot normalize"); rc = -3; break; }
             hipLaunchKernelGGL(finish_f64_kernel, dim3(2048), dim3(256), 0, st, d_vol, n, medd, pctd);
             if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { rc = -2; break; }
             h_stats[0] = medd;
+            h_stats[1] = pctd;
+            break;
+        }
+        if (legacy) {
+            int64_t ib, ia;
+            double wa;
+            const double wb = percentile_weights_legacy(P, &ib, &ia, &wa);
+            if (p.run(ib, &lo, nullptr) || p.run(ia, &hi, nullptr)) { rc = -2; break; }
+            const double x1 = (double)lo * wb;
+            const double x2 = (double)hi * wa;
+            const double pctd = x1 + x2;
+            if (pctd == 0.0) { snprintf(err, errlen, "Percentile value is zero - cannot normalize"); rc = -3; break; }
+            hipLaunchKernelGGL(finish_legacy_kernel, dim3(2048), dim3(256), 0, st, d_vol, n, med, (float)pctd, pctd);
+            if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { rc = -2; break; }
+            h_stats[0] = med;
             h_stats[1] = pctd;
             break;
         }

@@ -216,12 +216,13 @@ class Engine:
                                                _ptr(v4), self._stream()), "mica_stitch_tiles")
         return vol
 
-    def normalise_map_(self, vol: torch.Tensor, map_type: int = 0):
+    def normalise_map_(self, vol: torch.Tensor, map_type: int = 0, numpy_legacy: bool = False):
         """In place; returns (median, percentile).  Raises MicaHipError like the reference logs failure.
-        map_type: MICA_MAP_* of include/mica_hip.h (0 float32 map; 1/2/3 = int8/int16/uint16 values held as f32)."""
+        map_type: MICA_MAP_* of include/mica_hip.h (0 float32 map; 1/2/3 = int8/int16/uint16 values held as f32).
+        numpy_legacy: numpy 1.x arithmetic (float64 percentile weights, float64 clip / divide) instead of numpy 2's."""
         vol = _f32c(vol, "vol")
         st = (C.c_double * 2)()
-        self._check(self.lib.mica_normalise_map_typed(self._h, _ptr(vol), vol.numel(), int(map_type), st, self._stream()),
+        self._check(self.lib.mica_normalise_map_np(self._h, _ptr(vol), vol.numel(), int(map_type), int(bool(numpy_legacy)), st, self._stream()),
                     "mica_normalise_map")
         return float(st[0]), float(st[1])
 

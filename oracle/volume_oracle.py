@@ -134,10 +134,19 @@ def zoom_cubic(data, factors):
     return out.astype(data.dtype if data.dtype.kind == "f" else np.float64)
 
 
-def normalise_map(data, voxel_size=(1.0, 1.0, 1.0), target_voxel_size=1.0):
+def normalise_map(data, voxel_size=(1.0, 1.0, 1.0), target_voxel_size=1.0, numpy_legacy=False):
     """utils/preprocessing.py:111-133 (second witness:
     scripts_for_training_data/create_normalized_map.py:37-79).  Returns (normalised f32 map,
-    median, percentile) or raises ValueError where the reference logs an error."""
+    median, percentile) or raises ValueError where the reference logs an error.
+
+    numpy_legacy=True states what the SAME lines compute under numpy 1.x (the reference pins 1.19.1, environment.yml:8; this
+    container has 2.2.6, so the statement below is written out explicitly and is NOT pinned by a run - parity unpinned):
+      * np.percentile, 'linear' (numpy 1.19 lib/function_base.py, _quantile_ureduce_func): indices = q * (Nx - 1) in float64,
+        weights_above = indices - floor(indices), r = x_below * weights_below + x_above * weights_above - a float64 for every
+        input dtype (0-d operands promote like scalars), not numpy 2's float32 _lerp;
+      * value-based casting: `map < p` and `map >= p` compare in float32 with p rounded to float32 (same kind: the array wins);
+        `(map >= p) * p` is bool array x float64 scalar = a float64 array (the scalar's kind is higher), so the sum :131-132 and
+        the division :133 are float64, rounded once at astype(float32) :139."""
     from scipy.ndimage import zoom
 
     zf = [voxel_size[0] / target_voxel_size, voxel_size[1] / target_voxel_size,
@@ -149,6 +158,24 @@ def normalise_map(data, voxel_size=(1.0, 1.0, 1.0), target_voxel_size=1.0):
     pos = m[np.where(m > 0)]
     if len(pos) == 0:
         raise ValueError("No positive values found after thresholding")     # :163-165
+    if numpy_legacy:
+        srt = np.sort(pos.astype(np.float64) if pos.dtype.kind != "f" else pos)
+        nx = len(srt)
+        ind = (99.9 / 100.0) * (nx - 1)
+        below = int(np.floor(ind))
+        above = min(below + 1, nx - 1)
+        w_above = ind - below
+        w_below = 1.0 - w_above
+        pct = np.float64(srt[below]) * w_below + np.float64(srt[above]) * w_above
+        if pct == 0:
+            raise ValueError("Percentile value is zero - cannot normalize")
+        if m.dtype == np.float32:
+            p32 = np.float32(pct)
+            out = ((m < p32) * m).astype(np.float64) + (m >= p32) * np.float64(pct)
+        else:
+            out = (m < pct) * m + (m >= pct) * pct
+        out = out / np.float64(pct)
+        return out.astype(np.float32), float(median), float(pct)
     pct = np.percentile(pos, 99.9)                                          # :128
     if pct == 0:
         raise ValueError("Percentile value is zero - cannot normalize")     # :159-161

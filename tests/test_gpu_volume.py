@@ -93,6 +93,34 @@ def test_normalise_bit_exact_vs_golden(eng, golden_dir):
         eng.normalise_map_(torch.zeros((8, 8, 8), device="cuda"))
 
 
+@pytest.mark.parametrize("case", ["f32_64", "f32_odd", "i16", "u16"])
+def test_normalise_numpy_legacy_mode_vs_explicit_statement(eng, case):
+    """MICA_NUMPY_LEGACY on the normaliser: the arithmetic of numpy 1.x (the reference's pinned 1.19.1) as written out in
+    oracle/volume_oracle.py::normalise_map(numpy_legacy=True) - float64 percentile weights and weighted sum, float64 clip and
+    division for a float32 map too.  Bit-exact against that statement; the default (numpy 2) mode stays what the reference run in
+    this container produced, and the two modes differ by at most one float32 ulp.  PARITY UNPINNED for the legacy mode: no
+    fixture of the reference covers numpy 1.x, the statement is restated from numpy 1.19's source."""
+    rng = np.random.default_rng({"f32_64": 1, "f32_odd": 2, "i16": 3, "u16": 4}[case])
+    if case.startswith("f32"):
+        shape = (64, 64, 64) if case == "f32_64" else (31, 33, 35)
+        vol = ((rng.random(shape, dtype=np.float32) - 0.3) * 3.0).astype(np.float32)
+        data, mt = vol, 0
+    else:
+        shape = (24, 20, 28)
+        data = rng.integers(-300, 4000, shape).astype(np.int16) if case == "i16" else rng.integers(0, 5000, shape).astype(np.uint16)
+        vol, mt = data.astype(np.float32), 2 if case == "i16" else 3
+    ref, med, pct = vo.normalise_map(data, numpy_legacy=True)
+    t = torch.from_numpy(vol).cuda()
+    gm, gp = eng.normalise_map_(t, map_type=mt, numpy_legacy=True)
+    got = t.cpu().numpy()
+    assert gm == med and gp == pct
+    assert np.array_equal(got, ref)
+    t2 = torch.from_numpy(vol).cuda()
+    eng.normalise_map_(t2, map_type=mt)
+    d = np.abs(t2.cpu().numpy().astype(np.float64) - got.astype(np.float64))
+    assert d.max() <= np.spacing(np.float32(1.0))      # the two rule sets differ in the last bit at most
+
+
 def test_normalise_large_map_properties(eng):
     """256^3: output in [0,1], zeros exactly where x <= median, idempotent ranks."""
     g = torch.Generator(device="cuda").manual_seed(2)
