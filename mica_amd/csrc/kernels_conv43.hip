@@ -59,6 +59,19 @@ static_assert(Geo43::NSLOT % 64 == 0 && Geo43::NDMA == Geo43::NW * Geo43::DPW &&
               Geo43::PLANE == 18 * 64, "slab DMA plan: the lane / scalar split of the source offsets in the kernel assumes this geometry");
 
 typedef float floatx4w __attribute__((ext_vector_type(4)));
+#ifdef MICA43_CLOCKS
+// development: cycle stamps of one chunk (workgroup 8, its fourth item, chunk 10) per wave, read back by mica_debug_conv43 (tools/exp/clk43.py)
+__device__ unsigned g_mica43_clk[12 * 48];
+#define W43_STAMP(idx)                                                                                   \
+    do {                                                                                                 \
+        if (clk_on) {                                                                                    \
+            const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();         /* (HW_REG_SHADER_CYCLES reads 0 on gfx950) */ \
+            if (lane == 0) clk_lds[wave * 48 + (idx)] = t_;                                              \
+        }                                                                                                \
+    } while (0)
+#else
+#define W43_STAMP(idx) do {} while (0)
+#endif
 // development switches (timing experiments only, results are garbage; tools/exp/abl43.sh): -DMICA43_W_FIXED every weight fragment
 // load hits the same 4 KB per wave (L1 instead of the L2 stream); -DMICA43_SLAB_FIXED the slab DMAs wrap into the first 4 MB of
 // the operand (L2 instead of HBM); -DMICA43_NOEPI no output-transform passes
@@ -78,6 +91,17 @@ typedef float floatx4w __attribute__((ext_vector_type(4)));
 #else
 #define MICA43_SLABOFF(x) (x)
 #define MICA43_SLABBASE(b) (b)
+#endif
+// cache-policy experiments: -DMICA43_W_NT / -DMICA43_SLAB_NT put the `nt` modifier on the weight loads / the slab DMAs
+#ifdef MICA43_W_NT
+#define MICA43_WMOD " nt"
+#else
+#define MICA43_WMOD ""
+#endif
+#ifdef MICA43_SLAB_NT
+#define MICA43_SMOD " nt"
+#else
+#define MICA43_SMOD ""
 #endif
 #ifdef MICA43_NOEPI
 #define MICA43_EPI_PASSES 0
@@ -193,10 +217,10 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     do {                                                                                                                \
         const char* pb_ = MICA43_WBASE(base, off);                                                                      \
         const unsigned vo_ = w_common + (unsigned)((delta) & himask);                                                   \
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][0]) : "v"(vo_), "s"(pb_) : "memory");              \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(bq[set][1]) : "v"(vo_), "s"(pb_) : "memory");   \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(bq[set][2]) : "v"(vo_), "s"(pb_) : "memory");   \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:768" : "=v"(bq[set][3]) : "v"(vo_), "s"(pb_) : "memory");   \
+        asm volatile("global_load_dwordx4 %0, %1, %2" MICA43_WMOD : "=v"(bq[set][0]) : "v"(vo_), "s"(pb_) : "memory");              \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" MICA43_WMOD : "=v"(bq[set][1]) : "v"(vo_), "s"(pb_) : "memory");   \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" MICA43_WMOD : "=v"(bq[set][2]) : "v"(vo_), "s"(pb_) : "memory");   \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:768" MICA43_WMOD : "=v"(bq[set][3]) : "v"(vo_), "s"(pb_) : "memory");   \
     } while (0)
 #define MICA_BLOAD43_H(ps, base) MICA_BLOAD43(W43_HSET(ps), base, (ps) * psstride, (ps) == 4 ? 0 : 2 * BN * 16)
 #define MICA_BLOAD43_L(ps, base) MICA_BLOAD43(W43_LSET(ps), base, (ps) * psstride + 4 * ustride, 2 * BN * 16)
@@ -233,7 +257,7 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
         const int go_ = ok_ ? MICA43_SLABOFF((org).base + sc_ + dma_lane) : -1;                                         \
         unsigned long long sv_;                                                                                         \
         asm volatile("s_mov_b64 %0, exec\n\tv_cmp_lt_i32 vcc, -1, %1\n\ts_mov_b64 exec, vcc\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" \
-                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                                              \
+                     "global_load_lds_dwordx4 %1, %2" MICA43_SMOD "\n\ts_mov_b64 exec, %0"                                 \
                      : "=&s"(sv_) : "v"(go_), "s"(MICA43_SLABBASE(srcbase)), "s"(la_) : "memory", "vcc", "m0");          \
         if (ex_ && !ok_) *reinterpret_cast<uint4*>(smem + lo_ + lane * 16) = make_uint4(0, 0, 0, 0);                    \
     } while (0)
@@ -248,8 +272,17 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
         Item r;
         r.b = it / items_per_b;
         const int id = it - r.b * items_per_b;
-        r.nb = id % nnb;
-        const int seq = id / nnb;
+        // channel blocks: groups of NBG blocks run fastest (the CUs of an XCD round then share a tile's slab NBG-fold in L2, but stream
+        // NBG blocks' weights through it), the groups slowest
+#ifdef MICA43_NBG
+        const int nbg = MICA43_NBG < nnb ? MICA43_NBG : nnb;
+#else
+        const int nbg = nnb;
+#endif
+        const int ntiles = items_per_b / nnb;
+        const int nb_lo = id % nbg, rest = id / nbg;
+        const int seq = rest % ntiles;
+        r.nb = (rest / ntiles) * nbg + nb_lo;
         int tx, ty, tz;
         if (((nty & 7) | (((d.D + 3) >> 2) & 3)) == 0) {       // compact 8(y) x 4(z) blocks of tiles per XCD round (shared y/z halos in L2)
             const int inb = seq & 31, blk = seq >> 5, nby = nty >> 3;
@@ -284,6 +317,9 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     __syncthreads();
     int par = 0;
 
+#ifdef MICA43_CLOCKS
+    int item_no = 0;
+#endif
     for (;;) {
         const bool has_next = nitem < it_end;
         floatx4w acc[NF][NCT];
@@ -299,6 +335,11 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
         const char* wcur = cur.w;
 #pragma clang loop unroll(disable)
         for (int gch = 0; gch < total_chunks; ++gch) {
+#ifdef MICA43_CLOCKS
+            const bool clk_on = blockIdx.x == 8 && item_no == 3 && gch == 10;
+            unsigned* clk_lds = reinterpret_cast<unsigned*>(smem + 2 * Geo43::CH_BYTES + 16);
+#endif
+            W43_STAMP(0);
             const char* A = smem + par * G::CH_BYTES;
             const int nxt_off = (par ^ 1) * G::CH_BYTES;
             const bool last = gch + 1 == total_chunks;
@@ -331,6 +372,28 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                 const int ps = W43_PS(st), kind = W43_KIND(st);
                 // requests of this step, then the wait for the fragments it uses (in flight and NEWER than those: what was just
                 // requested, the fragments requested with them, and the slab DMAs issued since)
+#ifndef MICA43_HEARLY
+                // loads are spread over the steps (all twelve waves reach them together after the chunk barrier, and eight 1-KB requests
+                // per wave at once queue for > 1000 cycles in the vector memory pipeline: cycle stamps, tools/exp/clk43.py): step a requests L
+                // of this pair-step (used in c), step b requests H of the next pair-step (used from its a), x requests L of tap 8, y the
+                // next chunk's first H
+                if (kind == 0) {
+                    MICA_BLOAD43_L(ps, wcur);
+                    if (st == 0) W43_WAITN(4, W43_HSET(0)); else if (st == 3) W43_WAITN(4 + W43_NDMA(1) + W43_NDMA(2), W43_HSET(1));
+                    else if (st == 6) W43_WAITN(4 + W43_NDMA(4) + W43_NDMA(5), W43_HSET(2)); else W43_WAITN(4 + W43_NDMA(7) + W43_NDMA(8), W43_HSET(3));
+                } else if (kind == 1) {
+                    if (ps == 0) MICA_BLOAD43_H(1, wcur); else if (ps == 1) MICA_BLOAD43_H(2, wcur); else if (ps == 2) MICA_BLOAD43_H(3, wcur); else MICA_BLOAD43_H(4, wcur);
+                } else if (kind == 2) {
+                    if (st == 2) W43_WAITN(4 + W43_NDMA(0) + W43_NDMA(1), W43_LSET(0)); else if (st == 5) W43_WAITN(4 + W43_NDMA(3) + W43_NDMA(4), W43_LSET(1));
+                    else if (st == 8) W43_WAITN(4 + W43_NDMA(6) + W43_NDMA(7), W43_LSET(2)); else W43_WAITN(4 + W43_NDMA(9) + W43_NDMA(10), W43_LSET(3));
+                } else if (kind == 3) {
+                    MICA_BLOAD43_L(4, wcur);
+                    W43_WAITN(4 + W43_NDMA(10) + W43_NDMA(11), W43_HSET(4));
+                } else if (kind == 4) {
+                    MICA_BLOAD43_H(0, wnxt);
+                    W43_WAITN(4 + W43_NDMA(12), W43_LSET(4));
+                }
+#else
                 if (kind == 0) {
                     MICA_BLOAD43_L(ps, wcur);
                     if (ps == 0) MICA_BLOAD43_H(1, wcur); else if (ps == 1) MICA_BLOAD43_H(2, wcur); else if (ps == 2) MICA_BLOAD43_H(3, wcur); else MICA_BLOAD43_H(4, wcur);
@@ -349,8 +412,10 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                 } else if (kind == 4) {
                     W43_WAITN(4 + W43_NDMA(12), W43_LSET(4));
                 }
+#endif
                 static_assert(W43_NDMA(13) == 0, "no slab DMA in the last step: the chunk-end wait leaves exactly the next chunk's first H in flight");
                 __builtin_amdgcn_sched_barrier(0);
+                W43_STAMP(1 + 2 * st);
                 if (W43_SOFT && st == W43_DMA_FIRST) soft_wait(1, 12u * (unsigned)gch);      // every wave is done reading the buffer the DMAs overwrite
 #pragma unroll
                 for (int q = 0; q < W43_NDMA(st); ++q) MICA_SLAB_DMA43(nsrc, nxt_off, W43_DMA0(st) + q, org);
@@ -370,14 +435,19 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
                     const int fi = st * NF + f;                 // fragment index within the chunk; lives in ar[fi % (AD + 1)]
-                    if (f + AD < NF) ar[(fi + AD) % (AD + 1)] = W43_AFRAG(ab_cur, f + AD);
-                    else if (st + 1 < NS) ar[(fi + AD) % (AD + 1)] = W43_AFRAG(ab_nxt, f + AD - NF);
+                    // steps b and c (and x and y) read the same A fragments: they stay in the ring (slot = f, AD + 1 == NF) and the second
+                    // step only requests the fragments of the step after it
+                    static_assert(AD + 1 == NF, "ring slot == fragment index");
+                    const bool first_of_two = kind == 1 || kind == 3, second_of_two = kind == 2 || kind == 4;
+                    if (f + AD < NF) { if (!second_of_two) ar[(fi + AD) % (AD + 1)] = W43_AFRAG(ab_cur, f + AD); }
+                    else if (st + 1 < NS && !first_of_two) ar[(fi + AD) % (AD + 1)] = W43_AFRAG(ab_nxt, f + AD - NF);
 #pragma unroll
                     for (int c = 0; c < NCT; ++c)
                         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[f][c]) : "v"(ar[fi % (AD + 1)]), "v"(b1[c]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 ab_cur = ab_nxt;
+                W43_STAMP(2 + 2 * st);
             }
 #undef W43_ABASE
 #undef W43_AFRAG
@@ -387,8 +457,11 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                 soft_signal(1);
                 soft_wait(0, 12u * (unsigned)(gch + 1));                // every wave's DMAs for the next chunk have landed
             } else {
+                W43_STAMP(30);
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                W43_STAMP(31);
                 __syncthreads();
+                W43_STAMP(32);
                 // every wave is past the item's chunks: restart the counters (the epilogue's barriers publish it before the next item)
                 if (W43_SOFT && tid == 0) { sync_ctr[0] = 0; sync_ctr[1] = 0; }
                 if (W43_SOFT && MICA43_EPI_PASSES == 0) __syncthreads();
@@ -399,7 +472,7 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #ifdef MICA43_PRIO
         asm volatile("s_setprio 0");
 #endif
-        // the next item's first weight fragments were requested two steps ago: retire them here (the compiler cannot see them in flight)
+        // the next item's first weight fragments were requested in the last step: retire them here (the compiler cannot see them in flight)
         W43_WAIT(0, W43_HSET(0));
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU/LDS readers
 
@@ -511,6 +584,14 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                 }
                 __syncthreads();
             }
+#ifdef MICA43_CLOCKS
+            if (blockIdx.x == 8 && item_no == 3) {
+                __syncthreads();
+                const unsigned* cl = reinterpret_cast<const unsigned*>(smem + 2 * Geo43::CH_BYTES + 16);
+                for (int i = tid; i < 12 * 48; i += 768) g_mica43_clk[i] = cl[i];
+            }
+            ++item_no;
+#endif
             if (!has_next) break;
             item = nitem;
             nitem = nnitem;
@@ -541,6 +622,12 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 
 bool conv_wino43_eligible(int cout) { return cout % 128 == 0; }
 
+#ifdef MICA43_CLOCKS
+extern "C" int mica_debug_conv43(unsigned* h_out, int n) {
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_mica43_clk), sizeof(unsigned) * (n < 12 * 48 ? n : 12 * 48));
+}
+#endif
+
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null): f32 [B][P][cout][3].
 int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out,
                        int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
@@ -550,7 +637,11 @@ int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstri
     for (int i = 0; i < s.n; ++i) total += s.chunks[i];
     const int ntx = (d.W + 4 * Geo43::QX - 1) / (4 * Geo43::QX), nty = (d.H + Geo43::TY - 1) / Geo43::TY, ntz = (d.D + Geo43::TZ - 1) / Geo43::TZ,
               nnb = cout / 128;
+#ifdef MICA43_CLOCKS
+    const size_t lds = 2 * Geo43::CH_BYTES + 16 + 12 * 48 * 4;
+#else
     const size_t lds = 2 * Geo43::CH_BYTES + 16;          // two slab buffers + the soft-synchronisation counters
+#endif
     static unsigned long long seen = 0;
     static int cus_of[64] = {0};
     int dev = 0;
