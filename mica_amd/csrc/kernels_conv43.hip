@@ -92,17 +92,6 @@ __device__ unsigned g_mica43_clk[12 * 48];
 #define MICA43_SLABOFF(x) (x)
 #define MICA43_SLABBASE(b) (b)
 #endif
-// cache-policy experiments: -DMICA43_W_NT / -DMICA43_SLAB_NT put the `nt` modifier on the weight loads / the slab DMAs
-#ifdef MICA43_W_NT
-#define MICA43_WMOD " nt"
-#else
-#define MICA43_WMOD ""
-#endif
-#ifdef MICA43_SLAB_NT
-#define MICA43_SMOD " nt"
-#else
-#define MICA43_SMOD ""
-#endif
 #ifdef MICA43_NOEPI
 #define MICA43_EPI_PASSES 0
 #else
@@ -118,49 +107,24 @@ __device__ __forceinline__ const _Float16* chunk_base_wino43(const ConvSrcs& s, 
     return s.p[si] + ((int64_t)b * s.chunks_total[si] + s.chunk_off[si] + ch) * (int64_t)Vq * 192;
 }
 
+// Slab DMAs: every wave issues six per chunk, one per step in its first six steps.  Measured and dropped (profiles/r04_ablations_f43.txt):
+// two or three per step, all six in step 0, and moving all 72 to the four or six OLDEST waves - cycle stamps (tools/exp/clk43.py) show
+// the MFMA arbiter serving the three waves of a SIMD oldest first (waves 0-3 finish a chunk after ~8 K cycles and idle ~5 K at its
+// barrier, waves 8-11 are the critical path at 13 K) and a DMA costing its wave ~170 cycles, but with the old waves issuing all of them
+// the chunk took as long: the request path they occupy is the one the young waves' weight loads wait on.
 __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
                                                           const float* __restrict__ bias, float out_scale, float* __restrict__ out,
                                                           Dims d, int cout, int total_chunks, int ntx, int nty, int nnb,
                                                           int items_per_b, int total_items, float* __restrict__ stats_ws) {
     using G = Geo43;
     constexpr int BN = G::BN, NCT = 4, NS = 14, NF = 4;      // NS: steps per chunk (4 x (a, b, c) + x + y)
+    constexpr int DW = G::NW, DPW = G::NDMA / DW, DPS = DPW / 6;      // waves that issue slab DMAs, DMAs per wave and chunk, per step
+    static_assert(G::NDMA % DW == 0 && DPW % 6 == 0 && DPS == 1, "slab DMA plan: one per wave and step in the first six steps");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave % 6, wn = wave / 6;
-    // Soft chunk synchronisation (-DMICA43_SOFT; an experiment that did not pay).  A workgroup barrier per chunk couples twelve waves
-    // whose weight fragments and slab DMAs arrive at different times: without any synchronisation (results wrong) the kernel ran 8 %
-    // faster, with operands served from L1 / L2 the barrier cost 1 % (tools/exp/abl43.sh).  Here what the barrier guards is split
-    // into two counters in LDS with slack - and the kernel is 4 % slower than with the barrier, whatever the slack: the gain of the
-    // unsynchronised build comes from waves drifting many chunks apart, not from per-chunk jitter.
-    //   landed : += 1 by each wave in step 9, once its slab DMAs for the next chunk are in LDS (they were issued in steps 3..5 and are
-    //            older than the weight fragments that step has just waited for); a wave enters chunk c + 1 when landed >= 12 (c + 1)
-    //   done   : += 1 by each wave when its last LDS read of a chunk has returned; a wave issues its first slab DMA of chunk c (step
-    //            3, into the buffer that chunk c - 1 read) when done >= 12 c
-    // Every wait points at an earlier program point of the other waves, so there is no cycle; the last chunk of an item ends in
-    // the workgroup barrier as before (the epilogue needs one anyway) and the counters restart from zero per item.  The polls are
-    // bounded: a bookkeeping error must show up as a failed test, not as a hung GPU.
-    unsigned* sync_ctr = reinterpret_cast<unsigned*>(smem + 2 * Geo43::CH_BYTES);      // [0] landed, [1] done
-#ifdef MICA43_SOFT
-#define W43_SOFT 1
-#else
-#define W43_SOFT 0          /* measured 4 % SLOWER than the barrier at every slack (DMAs from step 1, 3, 6 or 8): off; kept as a switch */
-#endif
-    bool soft_broken = false;
-    auto soft_wait = [&](int which, unsigned target) {
-        if (soft_broken) return;
-        for (int spin = 0; spin < (1 << 14); ++spin) {                     // legitimate waits are a fraction of a chunk (microseconds)
-            const unsigned v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(sync_ctr + which));
-            if (v >= target) return;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        soft_broken = true;                                                // give up for good: wrong numbers, no hang
-    };
-    auto soft_signal = [&](int which) {
-        if (lane == 0) atomicAdd(sync_ctr + which, 1u);
-    };
-    if (tid == 0) { sync_ctr[0] = 0; sync_ctr[1] = 0; }
     const int Wq = (d.W + 3) >> 2;
     const int V = d.D * d.H * d.W, Vq = d.D * d.H * Wq;
 
@@ -202,25 +166,18 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #define W43_LSET(ps) ((ps) < 3 ? 2 : (ps) == 3 ? 0 : 1)
 #define W43_AOFF_TAP(tap) ((((tap) / 3) * G::PZ + ((tap) % 3) * G::QX) * 16)
 #define W43_PAIRDELTA(ps) ((ps) == 1 ? (G::PZ - 2 * G::QX) * 16 : G::QX * 16)
-    // the six slab DMAs of a chunk go out two per step in steps 3, 4, 5 (measured flat between "all in step 0" and "one per step"):
-    // late enough that the waves still finishing the PREVIOUS chunk are rarely waited for (W43_SOFT below), early enough to land
-#ifdef MICA43_DMA_FIRST
-#define W43_DMA_FIRST MICA43_DMA_FIRST
-#else
-#define W43_DMA_FIRST 3
-#endif
-#define W43_LANDED_STEP (W43_DMA_FIRST + 3 <= 9 ? 9 : 12)      /* a step whose weight wait covers loads issued after the last DMA */
-#define W43_NDMA(st) ((st) >= W43_DMA_FIRST && ((st) - W43_DMA_FIRST) * 2 < G::DPW ? 2 : 0)
-#define W43_DMA0(st) (((st) - W43_DMA_FIRST) * 2)
+    // slab DMA slots per wave and step (the first six steps of a chunk), and the first DMA index of a step
+#define W43_NDMA(st) ((st) >= 0 && (st) < 6 ? DPS : 0)
+#define W43_DMA0(st) ((st) * DPS)
     // one fragment set: four 16-cout column tiles, 256 B apart; `delta` (bytes, applied to k-groups 2,3) selects the second tap's units
 #define MICA_BLOAD43(set, base, off, delta)                                                                             \
     do {                                                                                                                \
         const char* pb_ = MICA43_WBASE(base, off);                                                                      \
         const unsigned vo_ = w_common + (unsigned)((delta) & himask);                                                   \
-        asm volatile("global_load_dwordx4 %0, %1, %2" MICA43_WMOD : "=v"(bq[set][0]) : "v"(vo_), "s"(pb_) : "memory");              \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" MICA43_WMOD : "=v"(bq[set][1]) : "v"(vo_), "s"(pb_) : "memory");   \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" MICA43_WMOD : "=v"(bq[set][2]) : "v"(vo_), "s"(pb_) : "memory");   \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:768" MICA43_WMOD : "=v"(bq[set][3]) : "v"(vo_), "s"(pb_) : "memory");   \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bq[set][0]) : "v"(vo_), "s"(pb_) : "memory");              \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(bq[set][1]) : "v"(vo_), "s"(pb_) : "memory");   \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:512" : "=v"(bq[set][2]) : "v"(vo_), "s"(pb_) : "memory");   \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:768" : "=v"(bq[set][3]) : "v"(vo_), "s"(pb_) : "memory");   \
     } while (0)
 #define MICA_BLOAD43_H(ps, base) MICA_BLOAD43(W43_HSET(ps), base, (ps) * psstride, (ps) == 4 ? 0 : 2 * BN * 16)
 #define MICA_BLOAD43_L(ps, base) MICA_BLOAD43(W43_LSET(ps), base, (ps) * psstride + 4 * ustride, 2 * BN * 16)
@@ -246,20 +203,19 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     const int dma_lane = (((lane >> 5) * 4) * Vq + dma_vy * Wq + dma_quad) * 16;
 #define MICA_SLAB_DMA43(srcbase, bufoff, k, org)                                                                        \
     do {                                                                                                                \
-        const int lo_ = (bufoff) + (((k) * G::NW + wave) * 64) * 16;                                                    \
+        const int ii_ = (k) * DW + dma_w;                        /* wave-uniform */                                      \
+        const int lo_ = (bufoff) + ii_ * 1024;                                                                          \
         const unsigned la_ = __builtin_amdgcn_readfirstlane(lds0 + lo_);                                                \
-        const int ii_ = (k) * G::NW + wave;                      /* wave-uniform */                                              \
         const int q_ = ii_ / 18, rem_ = ii_ - q_ * 18, vz_ = rem_ / 3, part_ = rem_ - vz_ * 3;                          \
         const int sc_ = (((part_ * 2) * 4 + q_) * Vq + vz_ * d.H * Wq) * 16;                                            \
-        const bool ex_ = true;                                                                                          \
         const bool ok_ = (org).i0 + dma_quad < Wq && (unsigned)((org).y0 + dma_vy) < (unsigned)d.H &&                   \
                          (unsigned)((org).z0 + vz_) < (unsigned)d.D;                                                    \
-        const int go_ = ok_ ? MICA43_SLABOFF((org).base + sc_ + dma_lane) : -1;                                         \
+        const int go_ = ok_ ? MICA43_SLABOFF((org).base + sc_ + dma_l) : -1;                                             \
         unsigned long long sv_;                                                                                         \
         asm volatile("s_mov_b64 %0, exec\n\tv_cmp_lt_i32 vcc, -1, %1\n\ts_mov_b64 exec, vcc\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" \
-                     "global_load_lds_dwordx4 %1, %2" MICA43_SMOD "\n\ts_mov_b64 exec, %0"                                 \
+                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"                                              \
                      : "=&s"(sv_) : "v"(go_), "s"(MICA43_SLABBASE(srcbase)), "s"(la_) : "memory", "vcc", "m0");          \
-        if (ex_ && !ok_) *reinterpret_cast<uint4*>(smem + lo_ + lane * 16) = make_uint4(0, 0, 0, 0);                    \
+        if (!ok_) *reinterpret_cast<uint4*>(smem + lo_ + lane * 16) = make_uint4(0, 0, 0, 0);                           \
     } while (0)
 
     struct Item {
@@ -272,17 +228,10 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
         Item r;
         r.b = it / items_per_b;
         const int id = it - r.b * items_per_b;
-        // channel blocks: groups of NBG blocks run fastest (the CUs of an XCD round then share a tile's slab NBG-fold in L2, but stream
-        // NBG blocks' weights through it), the groups slowest
-#ifdef MICA43_NBG
-        const int nbg = MICA43_NBG < nnb ? MICA43_NBG : nnb;
-#else
-        const int nbg = nnb;
-#endif
-        const int ntiles = items_per_b / nnb;
-        const int nb_lo = id % nbg, rest = id / nbg;
-        const int seq = rest % ntiles;
-        r.nb = (rest / ntiles) * nbg + nb_lo;
+        // the channel blocks of a tile run fastest: the CUs of an XCD round share the tile's slab in L2 (one block, or two, per pass over
+        // the tiles measured the same: profiles/r04_ablations_f43.txt)
+        r.nb = id % nnb;
+        const int seq = id / nnb;
         int tx, ty, tz;
         if (((nty & 7) | (((d.D + 3) >> 2) & 3)) == 0) {       // compact 8(y) x 4(z) blocks of tiles per XCD round (shared y/z halos in L2)
             const int inb = seq & 31, blk = seq >> 5, nby = nty >> 3;
@@ -311,8 +260,11 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 
     // prologue of the first item: slab chunk 0 -> buffer 0, H fragments of the first pair-step
     MICA_BLOAD43_H(0, cur.w);
+    {
+        const int dma_w = wave, dma_l = dma_lane;
 #pragma unroll
-    for (int k = 0; k < G::DPW; ++k) MICA_SLAB_DMA43(cur.src0, 0, k, cur);
+        for (int k = 0; k < DPW; ++k) MICA_SLAB_DMA43(cur.src0, 0, k, cur);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int par = 0;
@@ -337,9 +289,13 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
         for (int gch = 0; gch < total_chunks; ++gch) {
 #ifdef MICA43_CLOCKS
             const bool clk_on = blockIdx.x == 8 && item_no == 3 && gch == 10;
-            unsigned* clk_lds = reinterpret_cast<unsigned*>(smem + 2 * Geo43::CH_BYTES + 16);
+            unsigned* clk_lds = reinterpret_cast<unsigned*>(smem + 2 * Geo43::CH_BYTES);
 #endif
             W43_STAMP(0);
+            // laundered per chunk: as loop invariants the DMA source offsets of a wave are hoisted out of the item loop into VGPRs and
+            // SGPRs that this kernel does not have to spare
+            int dma_w = wave, dma_l = dma_lane;
+            asm volatile("" : "+s"(dma_w), "+v"(dma_l));
             const char* A = smem + par * G::CH_BYTES;
             const int nxt_off = (par ^ 1) * G::CH_BYTES;
             const bool last = gch + 1 == total_chunks;
@@ -372,7 +328,6 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                 const int ps = W43_PS(st), kind = W43_KIND(st);
                 // requests of this step, then the wait for the fragments it uses (in flight and NEWER than those: what was just
                 // requested, the fragments requested with them, and the slab DMAs issued since)
-#ifndef MICA43_HEARLY
                 // loads are spread over the steps (all twelve waves reach them together after the chunk barrier, and eight 1-KB requests
                 // per wave at once queue for > 1000 cycles in the vector memory pipeline: cycle stamps, tools/exp/clk43.py): step a requests L
                 // of this pair-step (used in c), step b requests H of the next pair-step (used from its a), x requests L of tap 8, y the
@@ -393,33 +348,11 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                     MICA_BLOAD43_H(0, wnxt);
                     W43_WAITN(4 + W43_NDMA(12), W43_LSET(4));
                 }
-#else
-                if (kind == 0) {
-                    MICA_BLOAD43_L(ps, wcur);
-                    if (ps == 0) MICA_BLOAD43_H(1, wcur); else if (ps == 1) MICA_BLOAD43_H(2, wcur); else if (ps == 2) MICA_BLOAD43_H(3, wcur); else MICA_BLOAD43_H(4, wcur);
-                    // H of this pair-step was requested a pair-step ago, in front of the DMAs of three steps and of the eight loads just issued
-                    if (st == 0) W43_WAITN(8, W43_HSET(0)); else if (st == 3) W43_WAITN(8 + W43_NDMA(0) + W43_NDMA(1) + W43_NDMA(2), W43_HSET(1));
-                    else if (st == 6) W43_WAITN(8 + W43_NDMA(3) + W43_NDMA(4) + W43_NDMA(5), W43_HSET(2));
-                    else W43_WAITN(8 + W43_NDMA(6) + W43_NDMA(7) + W43_NDMA(8), W43_HSET(3));
-                } else if (kind == 2) {
-                    // L of this pair-step was requested two steps ago, in front of the next H and the DMAs of steps a and b
-                    if (st == 2) W43_WAITN(4 + W43_NDMA(0) + W43_NDMA(1), W43_LSET(0)); else if (st == 5) W43_WAITN(4 + W43_NDMA(3) + W43_NDMA(4), W43_LSET(1));
-                    else if (st == 8) W43_WAITN(4 + W43_NDMA(6) + W43_NDMA(7), W43_LSET(2)); else W43_WAITN(4 + W43_NDMA(9) + W43_NDMA(10), W43_LSET(3));
-                } else if (kind == 3) {
-                    MICA_BLOAD43_L(4, wcur);
-                    MICA_BLOAD43_H(0, wnxt);
-                    W43_WAITN(8 + W43_NDMA(9) + W43_NDMA(10) + W43_NDMA(11), W43_HSET(4));
-                } else if (kind == 4) {
-                    W43_WAITN(4 + W43_NDMA(12), W43_LSET(4));
-                }
-#endif
                 static_assert(W43_NDMA(13) == 0, "no slab DMA in the last step: the chunk-end wait leaves exactly the next chunk's first H in flight");
                 __builtin_amdgcn_sched_barrier(0);
                 W43_STAMP(1 + 2 * st);
-                if (W43_SOFT && st == W43_DMA_FIRST) soft_wait(1, 12u * (unsigned)gch);      // every wave is done reading the buffer the DMAs overwrite
 #pragma unroll
                 for (int q = 0; q < W43_NDMA(st); ++q) MICA_SLAB_DMA43(nsrc, nxt_off, W43_DMA0(st) + q, org);
-                if (W43_SOFT && st == W43_LANDED_STEP) soft_signal(0);                                      // this wave's DMAs of the chunk have landed (see above)
                 const char* ab_nxt = ab_cur;
                 if (st + 1 < NS) ab_nxt = W43_ABASE(st + 1);
                 half8 (&b1)[NCT] = bq[(kind == 2 || kind == 4) ? W43_LSET(ps) : W43_HSET(ps)];
@@ -452,20 +385,11 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #undef W43_ABASE
 #undef W43_AFRAG
             // the slab DMAs of this chunk are older than the four weight loads (the next chunk's first H) still wanted in flight
-            if (W43_SOFT && !last) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads of the chunk have returned
-                soft_signal(1);
-                soft_wait(0, 12u * (unsigned)(gch + 1));                // every wave's DMAs for the next chunk have landed
-            } else {
-                W43_STAMP(30);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                W43_STAMP(31);
-                __syncthreads();
-                W43_STAMP(32);
-                // every wave is past the item's chunks: restart the counters (the epilogue's barriers publish it before the next item)
-                if (W43_SOFT && tid == 0) { sync_ctr[0] = 0; sync_ctr[1] = 0; }
-                if (W43_SOFT && MICA43_EPI_PASSES == 0) __syncthreads();
-            }
+            W43_STAMP(30);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            W43_STAMP(31);
+            __syncthreads();
+            W43_STAMP(32);
             par ^= 1;
             wcur = wnxt;
         }
@@ -587,7 +511,7 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #ifdef MICA43_CLOCKS
             if (blockIdx.x == 8 && item_no == 3) {
                 __syncthreads();
-                const unsigned* cl = reinterpret_cast<const unsigned*>(smem + 2 * Geo43::CH_BYTES + 16);
+                const unsigned* cl = reinterpret_cast<const unsigned*>(smem + 2 * Geo43::CH_BYTES);
                 for (int i = tid; i < 12 * 48; i += 768) g_mica43_clk[i] = cl[i];
             }
             ++item_no;
@@ -608,9 +532,6 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #undef W43_WAIT
 #undef W43_NDMA
 #undef W43_DMA0
-#undef W43_DMA_FIRST
-#undef W43_LANDED_STEP
-#undef W43_SOFT
 #undef W43_WAITN
 #undef W43_PS
 #undef W43_KIND
@@ -638,9 +559,9 @@ int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstri
     const int ntx = (d.W + 4 * Geo43::QX - 1) / (4 * Geo43::QX), nty = (d.H + Geo43::TY - 1) / Geo43::TY, ntz = (d.D + Geo43::TZ - 1) / Geo43::TZ,
               nnb = cout / 128;
 #ifdef MICA43_CLOCKS
-    const size_t lds = 2 * Geo43::CH_BYTES + 16 + 12 * 48 * 4;
+    const size_t lds = 2 * Geo43::CH_BYTES + 12 * 48 * 4;
 #else
-    const size_t lds = 2 * Geo43::CH_BYTES + 16;          // two slab buffers + the soft-synchronisation counters
+    const size_t lds = 2 * Geo43::CH_BYTES;          // two slab buffers
 #endif
     static unsigned long long seen = 0;
     static int cus_of[64] = {0};

@@ -22,19 +22,10 @@ t = np.array(buf, dtype=np.int64).reshape(12, 48)
 M = 1 << 32
 d = lambda a, b_: (a - b_) % M
 t0 = t[:, 0].min()
-print("wave  start  | per step: wait(incl. issue) / mfma-phase ...            | loop end  vmcnt  barrier  total")
+print("wave  start | first wait | steps 0-2  3-5  6-8  9-11  12-13 | loop end  vmcnt  barrier  total")
 for wv in range(12):
     r = t[wv]
-    parts = []
-    prev = r[0]
-    for st in range(14):
-        parts.append(f"{d(r[1 + 2 * st], prev):4d}/{d(r[2 + 2 * st], r[1 + 2 * st]):4d}")
-        prev = r[2 + 2 * st]
-    print(f"{wv:2d}  {d(r[0], t0):6d} | " + " ".join(parts) + f" | {d(r[30], r[0]):6d} {d(r[31], r[30]):5d} {d(r[32], r[31]):6d} {d(r[32], r[0]):6d}")
-tot = np.array([d(t[w_][32], t[w_][0]) for w_ in range(12)])
-wait = np.array([sum(d(t[w_][1 + 2 * st], t[w_][2 * st]) for st in range(14)) for w_ in range(12)])
-bar = np.array([d(t[w_][32], t[w_][31]) for w_ in range(12)])
-print("chunk cycles per wave", tot.tolist())
-print("sum of waits per wave", wait.tolist())
-print("barrier wait per wave", bar.tolist())
-print("ideal MFMA cycles per SIMD and chunk: 3 waves x 224 MFMAs x 16 =", 3 * 224 * 16)
+    marks = [r[1], r[2 + 4], r[2 + 10], r[2 + 16], r[2 + 22], r[2 + 26]]
+    seg = [d(marks[i + 1], marks[i]) for i in range(5)]
+    print(f"{wv:2d}  {d(r[0], t0):6d} | {d(r[1], r[0]):6d} | " + " ".join(f"{v:6d}" for v in seg) + f" | {d(r[30], r[0]):6d} {d(r[31], r[30]):5d} {d(r[32], r[31]):6d} {d(r[32], r[0]):6d}")
+print("ideal MFMA cycles per SIMD and chunk: 3 waves x 224 MFMAs x 16 =", 3 * 224 * 16, "; per wave alone 3584; a 3-step segment alone 768")
