@@ -156,6 +156,36 @@ def test_record_exchange_step_loop_gloo_world2(tmp_path):
         assert torch.equal(rec, _producer(first, 2) + 100.0 * k)
 
 
+def _force_worker(rank, world, port, T, B, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    got, stats = {}, {}
+    sharded_records(_producer, lambda rec, first: got.__setitem__(first, rec.clone()), T, B, (2, 4, 4, 4), torch.device("cpu"),
+                    force_collective=True, stats=stats)
+    torch.save({"got": got, "stats": stats}, out_path)
+    dist.destroy_process_group()
+
+
+def test_force_collective_in_a_group_of_one_rank(tmp_path):
+    """`force_collective`: a process group of ONE rank still takes the collective path of RecordExchange (receive buffers, an
+    all_gather_into_tensor per round, work.wait(), slot reuse) - the switch that lets the RCCL branch run on a one-GPU box
+    (tests/test_gpu_configs.py::test_config2_rccl_branch_single_rank_equals_plain_pipeline; here over gloo on CPU tensors)."""
+    T, B = 13, 4
+    port = 29500 + (os.getpid() + 311) % 2000
+    out = str(tmp_path / "force.pt")
+    mp.spawn(_force_worker, args=(1, port, T, B, out), nprocs=1, join=True)
+    r = torch.load(out, weights_only=True)
+    assert r["stats"]["collectives"] == len(batch_plan(T, B)) == 4 and r["stats"]["world"] == 1 and r["stats"]["backend"] == "gloo"
+    single = {}
+    st = {}
+    sharded_records(_producer, lambda rec, first: single.__setitem__(first, rec.clone()), T, B, (2, 4, 4, 4), torch.device("cpu"), stats=st)
+    assert st["collectives"] == 0                            # no group, no switch: the plain path
+    assert sorted(r["got"]) == sorted(single)
+    for f in single:
+        assert torch.equal(r["got"][f], single[f])
+
+
 def _pdb_line(rec, serial, name, altloc, resname, chain, resseq, x, y, z, occ=1.0):
     nm = name if len(name) == 4 else " " + name.ljust(3)
     return "%-6s%5d %4s%1s%3s %1s%4d    %8.3f%8.3f%8.3f%6.2f%6.2f          %2s\n" % (
