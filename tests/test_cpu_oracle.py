@@ -318,6 +318,40 @@ def test_inline_asm_weight_prefetch_is_hazard_free(tmp_path):
     assert spills and max(spills) == 0, spills
 
 
+def test_inline_asm_weight_prefetch_of_the_f43_kernel_is_hazard_free(tmp_path):
+    """conv_wino43_kernel (kernels_conv43.hip): the same audit.  Per chunk and wave 14 steps of 16 MFMAs, ten weight-fragment sets in
+    three register sets (40 asm loads), six slab DMAs, 36 A-fragment reads; the waits a step places leave exactly the fragments
+    requested since and the DMAs issued since in flight; one copy of the chunk body, no spill anywhere in the file."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "mica_amd", "csrc", "kernels_conv43.hip")
+    asm = str(tmp_path / "kernels_conv43.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", asm, src],
+                          stderr=subprocess.DEVNULL)
+    text = open(asm).read()
+    m = re.search(r"^_ZN4mica18conv_wino43_kernelE.*?s_endpgm", text, flags=re.S | re.M)
+    assert m
+    body = m.group(0)
+    part = str(tmp_path / "wino43.s")
+    open(part, "w").write(body)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), part], text=True)
+    assert "violations: 0" in out, out[-2000:]
+    assert body.count("v_mfma_f32_16x16x32_f16") == 224 and "scratch_" not in body
+    # the chunk loop: from the first to the last MFMA
+    lines = body.split("\n")
+    idx = [i for i, l in enumerate(lines) if "v_mfma_f32_16x16x32_f16" in l]
+    loop = "\n".join(lines[idx[0] - 120:idx[-1] + 1])
+    assert loop.count("global_load_lds_dwordx4") == 6
+    assert loop.count("ds_read_b128") + loop.count("ds_load_b128") in (36, 37, 38, 39)        # 36 per chunk; the first few may sit above the window
+    loads = len(re.findall(r"global_load_dwordx4", loop))
+    assert loads == 40, loads
+    spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
+    assert spills and max(spills) == 0, spills
+
+
 @pytest.mark.parametrize("shape,factors", [((6, 7, 5), (1.5, 1.25, 0.8)), ((9, 4, 11), (0.83, 0.83, 0.83)), ((5, 5, 5), (1.0, 1.0, 1.0)),
                                            ((4, 1, 8), (47.0, 1.0, 0.5)), ((12, 10, 3), (1.07, 2.0, 1.3))])
 def test_zoom_restatement_is_bit_exact_vs_scipy(shape, factors):
