@@ -46,8 +46,11 @@ constexpr int C1_NT = 256;                              // threads per workgroup
 constexpr int C1_STAGE = 2 * 4 * C1_ROWS * 16;          // bytes per stage
 constexpr int C1_TS = 68;                               // floats per row of the epilogue staging tile (64 + pad)
 constexpr int C1_TBYTES = C1_ROWS * C1_TS * 4;
-constexpr int C1_TAB = 2 * 512 * 2 * 4;                 // (mean, rstd) of up to 512 channels for two sources
-constexpr int C1_LDS = (C1_TBYTES > 2 * C1_STAGE ? C1_TBYTES : 2 * C1_STAGE) + C1_TAB;
+constexpr int C1_TAB = 2 * 512 * 2 * 4;                 // (mean, rstd) of up to 512 channels for two sources: the largest table
+constexpr int C1_BASE = (C1_TBYTES > 2 * C1_STAGE ? C1_TBYTES : 2 * C1_STAGE);      // stages / epilogue tile
+constexpr int C1_LDS = C1_BASE + C1_TAB;
+// The norm table is sized per launch (tab_stride = channels of the widest RAW source, none for split sources): with the full 8 KB
+// a workgroup needs 42.8 KB and three fit a CU; a 512-channel single source needs 4 KB (38.9 KB: four fit), the stem fusion none.
 
 __device__ __forceinline__ void c1_split8(const float (&y)[8], half8& hi, half8& lo, int& bad, float ascale) {
     mica_split8(y, hi, lo, bad, ascale);
@@ -57,9 +60,9 @@ __device__ __forceinline__ void c1_split8(const float (&y)[8], half8& hi, half8&
 template <int NCT, int WINO>
 __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x1_kernel(Conv1Srcs src, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
                                                       const float* __restrict__ bias, float out_scale, float* __restrict__ out_raw,
-                                                      SplitView wino, Dims d, int cout, int total_chunks, SplitEnc enc, float out_ascale) {
+                                                      SplitView wino, Dims d, int cout, int total_chunks, SplitEnc enc, float out_ascale, int tab_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* tab = reinterpret_cast<float2*>(smem + C1_LDS - C1_TAB);
+    float2* tab = reinterpret_cast<float2*>(smem + C1_BASE);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
         if (s.kind == 1) {
             const int Cs = s.chunks_total * 16;
             for (int ch = tid; ch < Cs; ch += C1_NT)
-                tab[si * 512 + ch] = s.mean ? make_float2(s.mean[(int64_t)b * Cs + ch], s.rstd[(int64_t)b * Cs + ch]) : make_float2(0.f, 1.f);
+                tab[si * tab_stride + ch] = s.mean ? make_float2(s.mean[(int64_t)b * Cs + ch], s.rstd[(int64_t)b * Cs + ch]) : make_float2(0.f, 1.f);
         }
     }
 
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
                 const bool live = v0 + row < V;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float2 mr = tab[w.si * 512 + ch0 + j];
+                    const float2 mr = tab[w.si * tab_stride + ch0 + j];
                     float t = (y[j] - mr.x) * mr.y;
                     if (s.relu) t = fmaxf(t, 0.f);
                     y[j] = live ? t : 0.f;
@@ -333,8 +336,12 @@ static void launch_conv1x1_t(const Conv1Srcs& src, const _Float16* wpk, int64_t 
     }
     const int V = d.D * d.H * d.W;
     dim3 grid((V + C1_ROWS - 1) / C1_ROWS, B);
-    hipLaunchKernelGGL((conv1x1_kernel<NCT, WINO>), grid, dim3(C1_NT), C1_LDS, st, src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, d, cout,
-                       total, enc, out_ascale);
+    int tab_stride = 0;                                   // channels of the widest raw source (multiple of 16, <= 512)
+    for (int i = 0; i < src.n; ++i)
+        if (src.s[i].kind == 1 && src.s[i].chunks_total * 16 > tab_stride) tab_stride = src.s[i].chunks_total * 16;
+    const int lds = C1_BASE + src.n * tab_stride * (int)sizeof(float2);
+    hipLaunchKernelGGL((conv1x1_kernel<NCT, WINO>), grid, dim3(C1_NT), lds, st, src, wpk, wpk_bstride, bias, out_scale, out_raw, wino, d, cout,
+                       total, enc, out_ascale, tab_stride);
 }
 
 // cout in {64, 128, 256}.  Exactly one of out_raw / wino.p is given; wino needs conv1x1_can_emit_wino(d).
