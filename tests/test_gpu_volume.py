@@ -171,6 +171,46 @@ def test_predictor_end_to_end_vs_reference_golden(tmp_path, weights, golden_dir)
     assert os.path.exists(tmp_path / "out" / "results" / "grids" / "backbone_probability.npy")
 
 
+def test_file_predictor_staged_uploads_over_many_runs(tmp_path, weights):
+    """The file-based predictor uploads run r + 1 from one of two pinned staging pairs while run r computes; a pair is rewritten
+    only after a host-side wait on the event of the upload that last read it (advisor, round 3).  Seven runs of two tiles each, every
+    tile different (so a staging buffer rewritten too early would show), half of the tiles without atoms: equal to the disk-free
+    pipeline on the same map bit for bit."""
+    from mica_amd.af3_encoding import CHANNEL_NAMES
+    from mica_amd.engine import Engine
+    from mica_amd.pipeline import VolumePredictor
+    from mica_amd.predict import CryoEMPredictor
+    shape = (330, 48, 90)                                   # 7 x 1 x 2 = 14 tiles
+    vol = synth_density(shape, 71)
+    af = synth_af(shape, 71, 2e-3)
+    af[:, :, :, 45:] = 0
+    tiles, idx = vo.tile_volume(vol, 48, 8)
+    gdir = tmp_path / "grids" / "normalized_map_grids"
+    os.makedirs(gdir)
+    for t, (i, j, k, di, dj, dk) in enumerate(idx):
+        np.savez(gdir / f"normalized_map_grid_i{i}_j{j}_k{k}.npz", grid=tiles[t], i=i, j=j, k=k, di=di, dj=dj, dk=dk,
+                 orig_shape=shape, grid_size=48, padding=8)
+    for c, name in enumerate(CHANNEL_NAMES):
+        cdir = tmp_path / "grids" / "AF3_encoding_grids" / f"{name}_grids"
+        os.makedirs(cdir)
+        tl, _ = vo.tile_volume(af[c], 48, 8)
+        for t, (i, j, k, di, dj, dk) in enumerate(idx):
+            np.savez(cdir / f"{name}_grid_i{i}_j{j}_k{k}.npz", grid=tl[t], i=i, j=j, k=k, di=di, dj=dj, dk=dk, orig_shape=shape,
+                     grid_size=48, padding=8)
+    ck = str(tmp_path / "ckpt.pth")
+    torch.save({"epoch": 0, "model_state_dict": {"module." + k: torch.from_numpy(v.copy()) for k, v in weights.items()}}, ck)
+    pred = CryoEMPredictor(model_path=ck, grids_path=str(tmp_path / "grids") + "/", output_path=str(tmp_path / "out"), save_output=False,
+                           device="cuda", quiet=True, batch_size=2)
+    ok, vols = pred.run_prediction()
+    assert ok and pred.sample_count == 14
+    e = Engine(0, max_batch=2, tile_size=64)
+    e.load_state_dict(weights)
+    mem = VolumePredictor(e, 48, 8, batch=2).predict_volume(torch.from_numpy(vol).cuda(), torch.from_numpy(af).cuda())
+    for k in vols:
+        assert np.array_equal(vols[k], mem[k].cpu().numpy()), k
+    e.close()
+
+
 def test_in_memory_pipeline_equals_tile_files_and_gating_is_per_tile(eng, weights):
     """VolumePredictor (no disk) on a map whose AF3 encodings touch only one of the two tiles."""
     from mica_amd.pipeline import VolumePredictor
