@@ -422,3 +422,16 @@ def test_model_oracle_matches_reference_on_stress_goldens(golden_dir, kind):
         ref = g[key]
         scale = np.maximum(np.abs(ref), np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
         assert np.max(np.abs(got.numpy() - ref) / scale) < 1e-4
+
+
+def test_whole_network_winograd_emulation_supports_the_shipped_choice(golden_dir):
+    """oracle/wino_network.py (the emulation that decided which layers run on Winograd F(4,3), DESIGN.md section 4 "Round 4") on one
+    weight set: the shipped choice - F(4,3) with the balanced points on encoder.2, F(2,3) elsewhere - stays inside the 1e-4 bar
+    against the reference's float32 logits and against the float64 truth, and F(4,3) everywhere with the textbook points is
+    measurably worse (rms distance from the truth)."""
+    from oracle import wino_network as wn
+    torch.set_num_threads(8)
+    e32, e64, ref, rms, ref_rms = wn.run_case("f43s@e2", "w2022g6", "model_S16_af.npz", 2022, 6.0, golden_dir)
+    assert max(e32) < 1e-4 and max(e64) < 1e-4
+    _, _, _, rms_all, _ = wn.run_case("f43", "w2022g6", "model_S16_af.npz", 2022, 6.0, golden_dir)
+    assert rms_all > 1.3 * rms and rms < 1.5 * ref_rms
