@@ -49,10 +49,13 @@ int mica_abi_version(void);
 
 /* ---- context ---------------------------------------------------------------------------- */
 /* Allocates the activation workspace for up to max_batch tiles of tile_size^3 voxels in flight (about 4.6 GB per 64^3 tile).
- * Limits: 1 <= max_batch <= 64; tiles are CUBIC, 4 <= tile_size <= 128 (the reference's MICA.forward is size-agnostic and its
- * predictor uses 64 = grid 48 + 2 x 8, utils/predict.py; non-cubic tiles are refused, not silently reshaped); the network is the
+ * Limits: 1 <= max_batch <= 64; tile edges in [4, 128] (cubic here, any box with mica_create_dims; the reference's predictor uses
+ * 64 = grid 48 + 2 x 8, utils/predict.py); the network is the
  * reference's base_filters = 64 configuration (models/model.py:262-293), the only one its checkpoints have.                    */
 int mica_create(int device, int max_batch, int tile_size, mica_ctx** out);
+/* The same for a non-cubic tile [d][h][w] (MICA.forward is size-agnostic, models/model.py:331-348: the network is fully
+ * convolutional with global pools); the tiler / stitch entry points keep the reference's cubic windows.                          */
+int mica_create_dims(int device, int max_batch, int tile_d, int tile_h, int tile_w, mica_ctx** out);
 void mica_destroy(mica_ctx* ctx);
 const char* mica_last_error(const mica_ctx* ctx);   /* ctx may be NULL: last create() error */
 int64_t mica_workspace_bytes(const mica_ctx* ctx);

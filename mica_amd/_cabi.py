@@ -22,6 +22,7 @@ _DP = C.POINTER(C.c_double)
 SIGNATURES = {
     "mica_abi_version": (_I, []),
     "mica_create": (_I, [_I, _I, _I, C.POINTER(_P)]),
+    "mica_create_dims": (_I, [_I, _I, _I, _I, _I, C.POINTER(_P)]),
     "mica_destroy": (None, [_P]),
     "mica_last_error": (C.c_char_p, [_P]),
     "mica_workspace_bytes": (_L, [_P]),

@@ -548,8 +548,14 @@ const char* mica_last_error(const mica_ctx* ctx) { return ctx ? ctx->err.c_str()
 int64_t mica_workspace_bytes(const mica_ctx* ctx) { return ctx ? ctx->bytes : 0; }
 
 int mica_create(int device, int max_batch, int tile_size, mica_ctx** out) {
-    if (!out || max_batch < 1 || max_batch > 64 || tile_size < 4 || tile_size > 128) {
-        g_create_err = "mica_create: bad argument";
+    return mica_create_dims(device, max_batch, tile_size, tile_size, tile_size, out);
+}
+
+int mica_create_dims(int device, int max_batch, int td, int th, int tw, mica_ctx** out) {
+    // the workspace is sized for the cubic tile that bounds (td, th, tw): every size formula below is monotonic in each edge
+    const int tile_size = std::max(td, std::max(th, tw));
+    if (!out || max_batch < 1 || max_batch > 64 || std::min(td, std::min(th, tw)) < 4 || tile_size > 128) {
+        g_create_err = "mica_create: bad argument (1 <= max_batch <= 64, tile edges in [4, 128])";
         return MICA_ERR_ARG;
     }
     int ndev = 0;
@@ -570,8 +576,8 @@ int mica_create(int device, int max_batch, int tile_size, mica_ctx** out) {
     c->device = device;
     c->maxB = max_batch;
     c->S = tile_size;
-    c->d = Dims{tile_size, tile_size, tile_size};
-    c->V = tile_size * tile_size * tile_size;
+    c->d = Dims{td, th, tw};
+    c->V = td * th * tw;
     const int64_t BV = (int64_t)max_batch * c->V;
     int r = 0;
     // wino layout holds 4 transformed values per output pair: 2x the plain bytes (pairs = ceil(W/2) per row)

@@ -23,8 +23,10 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 class Engine:
-    def __init__(self, device: int | str | torch.device = 0, max_batch: int = 1, tile_size: int = 64, conv_variant: int | None = None):
-        """conv_variant: None = the library default (encoder.2's 3x3x3 convs on the F(4,3) kernel; MICA_F43=0 in the environment turns
+    def __init__(self, device: int | str | torch.device = 0, max_batch: int = 1, tile_size=64, conv_variant: int | None = None):
+        """tile_size: an int (cubic tiles, what the tiler / predictor use) or (D, H, W) for the inner boundary alone
+        (`forward_logits`: MICA.forward is size-agnostic).
+        conv_variant: None = the library default (encoder.2's 3x3x3 convs on the F(4,3) kernel; MICA_F43=0 in the environment turns
         that off), 0 = every 3x3x3 conv on the F(2,3) kernel, 1 = encoder.2 on F(4,3).  Fixed before the weights are loaded."""
         if not torch.cuda.is_available():
             raise MicaHipError("no HIP device visible: mica_amd runs on MI355X (gfx950) only, there is no CPU fallback")
@@ -33,10 +35,14 @@ class Engine:
             raise MicaHipError(f"device {device!r} is not a GPU; mica_amd has no CPU path")
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         self.lib = _cabi.load_library()
-        self.max_batch, self.tile_size = int(max_batch), int(tile_size)
+        self.max_batch = int(max_batch)
+        self.tile_shape = tuple(int(v) for v in tile_size) if isinstance(tile_size, (tuple, list)) else (int(tile_size),) * 3
+        if len(self.tile_shape) != 3:
+            raise MicaHipError(f"tile_size must be an int or (D, H, W), got {tile_size!r}")
+        self.tile_size = self.tile_shape[0] if len(set(self.tile_shape)) == 1 else None      # None: non-cubic, forward_logits only
         h = C.c_void_p()
         with torch.cuda.device(self.device):          # the ambient current device of the caller is left alone
-            r = self.lib.mica_create(self.device.index, self.max_batch, self.tile_size, C.byref(h))
+            r = self.lib.mica_create_dims(self.device.index, self.max_batch, *self.tile_shape, C.byref(h))
         if r != 0:
             raise MicaHipError(f"mica_create failed ({r}): {self.lib.mica_last_error(None).decode()}")
         self._h = h
@@ -107,20 +113,25 @@ class Engine:
         if af is not None and af_mode == AF_BATCH and n > self.max_batch:
             raise MicaHipError(f"AF_BATCH over {n} tiles needs an engine with max_batch >= {n} (this one: {self.max_batch})")
 
+    def _cubic(self, what):
+        if self.tile_size is None:
+            raise MicaHipError(f"{what}: this engine was built for non-cubic tiles {self.tile_shape}; only forward_logits takes those")
+        return self.tile_size
+
     def forward_logits(self, exp_map: torch.Tensor, af: torch.Tensor | None, af_mode: int = AF_BATCH):
-        S = self.tile_size
+        dims = self.tile_shape
         exp_map = _f32c(exp_map, "exp_map")
         B = exp_map.shape[0]
-        if tuple(exp_map.shape) != (B, 1, S, S, S):
-            raise MicaHipError(f"exp_map must be [B,1,{S},{S},{S}], got {tuple(exp_map.shape)}")
+        if tuple(exp_map.shape) != (B, 1, *dims):
+            raise MicaHipError(f"exp_map must be [B,1,{dims[0]},{dims[1]},{dims[2]}], got {tuple(exp_map.shape)}")
         if af is not None:
             af = _f32c(af, "af_features")
-            if tuple(af.shape) != (B, 24, S, S, S):
-                raise MicaHipError(f"af_features must be [B,24,{S},{S},{S}], got {tuple(af.shape)}")
+            if tuple(af.shape) != (B, 24, *dims):
+                raise MicaHipError(f"af_features must be [B,24,{dims[0]},{dims[1]},{dims[2]}], got {tuple(af.shape)}")
         self._check_batch_mode(B, af, af_mode)
-        bb = torch.empty((B, 4, S, S, S), dtype=torch.float32, device=self.device)
+        bb = torch.empty((B, 4, *dims), dtype=torch.float32, device=self.device)
         ca = torch.empty_like(bb)
-        aa = torch.empty((B, 21, S, S, S), dtype=torch.float32, device=self.device)
+        aa = torch.empty((B, 21, *dims), dtype=torch.float32, device=self.device)
         self._begin_forward()
         for b0 in range(0, B, self.max_batch):
             b1 = min(B, b0 + self.max_batch)
@@ -132,7 +143,7 @@ class Engine:
 
     def forward_tiles(self, map_tiles: torch.Tensor, af_tiles: torch.Tensor | None, out=None, af_mode: int = AF_PER_TILE):
         """map_tiles f32[T,S^3-shaped], af_tiles f32[T,24,...] or None -> (bb_prob[T,S,S,S], ca_prob, aa_prob[T,20,S,S,S], aa_pred)."""
-        S = self.tile_size
+        S = self._cubic("forward_tiles")
         T = map_tiles.shape[0]
         map_tiles = _f32c(map_tiles, "map_tiles").view(T, 1, S, S, S)
         if af_tiles is not None:
@@ -156,7 +167,7 @@ class Engine:
     def forward_records(self, map_tiles: torch.Tensor, af_tiles: torch.Tensor | None, rec: torch.Tensor, af_mode: int = AF_PER_TILE):
         """As forward_tiles, written straight into rec f32[T,23,S,S,S] (bb, ca, aa_pred, aa_prob x20 per tile): the record layout
         stitch_tiles and the multi-GPU exchange use."""
-        S = self.tile_size
+        S = self._cubic("forward_records")
         T = map_tiles.shape[0]
         map_tiles = _f32c(map_tiles, "map_tiles").view(T, 1, S, S, S)
         if af_tiles is not None:
@@ -174,7 +185,7 @@ class Engine:
 
     def postprocess(self, bb, ca, aa):
         B = bb.shape[0]
-        S = self.tile_size
+        S = self._cubic("postprocess")
         bb, ca, aa = _f32c(bb, "bb"), _f32c(ca, "ca"), _f32c(aa, "aa")
         o = (torch.empty((B, S, S, S), dtype=torch.float32, device=self.device),
              torch.empty((B, S, S, S), dtype=torch.float32, device=self.device),

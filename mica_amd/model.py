@@ -52,21 +52,23 @@ class MICA:
     def state_dict(self):
         return dict(self._sd or {})
 
-    def _engine(self, S: int) -> Engine:
+    def _engine(self, dims) -> Engine:
         if self._sd is None:
             raise MicaHipError("MICA: load_state_dict() first (no trained weights ship with the package)")
-        if S not in self._engines:
-            e = Engine(self.device or 0, max_batch=self.max_batch, tile_size=S)
+        dims = tuple(int(v) for v in dims)
+        if dims not in self._engines:
+            e = Engine(self.device or 0, max_batch=self.max_batch, tile_size=dims)
             e.load_state_dict(self._sd)
-            self._engines[S] = e
-        return self._engines[S]
+            self._engines[dims] = e
+        return self._engines[dims]
 
     def forward(self, exp_map: torch.Tensor, af_features: torch.Tensor | None = None):
-        """exp_map f32[B,1,S,S,S], af_features f32[B,24,S,S,S] or None -> three NCDHW logit tensors.
+        """exp_map f32[B,1,D,H,W], af_features f32[B,24,D,H,W] or None -> three NCDHW logit tensors (any box with edges in
+        [4, 128], as the reference's fully convolutional forward; one engine is kept per tile shape).
         The AF3 gate is batch-wide, exactly as model.py:60."""
-        if exp_map.dim() != 5 or exp_map.shape[1] != 1 or len(set(exp_map.shape[2:])) != 1:
-            raise MicaHipError(f"exp_map must be [B,1,S,S,S], got {tuple(exp_map.shape)}")
-        e = self._engine(exp_map.shape[2])
+        if exp_map.dim() != 5 or exp_map.shape[1] != 1:
+            raise MicaHipError(f"exp_map must be [B,1,D,H,W], got {tuple(exp_map.shape)}")
+        e = self._engine(exp_map.shape[2:])
         dev = e.device
         af = None if af_features is None else af_features.to(dev, torch.float32)
         return e.forward_logits(exp_map.to(dev, torch.float32), af, AF_BATCH)
