@@ -233,6 +233,34 @@ def test_af3_pdb_reader_and_oracle_rasteriser(tmp_path):
     assert v2[0, 0, 0, 3] == 1
 
 
+@pytest.mark.parametrize("name,atoms", [("model.pdb", 209), ("model.rebuilt.pdb", None)])
+def test_pdb_reader_on_the_pdb_files_the_reference_ships(name, atoms):
+    """The only PDB files inside the reference (modules/pulchra304/examples: a CA trace without occupancy / B-factor columns
+    and a rebuilt all-atom model with a blank chain id) through the fixed-column reader, against an independent
+    whitespace-split reading of the same records.  Bio.PDB is absent, so this pins the reader's handling of real short
+    records, not Bio's semantics (that part stays 'parity unpinned'); skipped where /root/reference is absent."""
+    import os
+    from mica_amd import af3_encoding as ae
+    path = os.path.join("/root/reference/modules/pulchra304/examples", name)
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    ref_names, ref_res, ref_xyz = [], [], []
+    for line in open(path):
+        if line.startswith("ATOM"):
+            tok = line.split()
+            has_chain = not tok[4].lstrip("-").isdigit()
+            ref_names.append(tok[2])
+            ref_res.append(tok[3])
+            ref_xyz.append([float(v) for v in tok[(6 if has_chain else 5):(9 if has_chain else 8)]])
+    coords, names, res = ae.read_pdb_atoms(path)
+    assert names == ref_names and res == ref_res and len(names) > 100
+    if atoms is not None:
+        assert len(names) == atoms and set(names) == {"CA"}
+    assert coords.dtype == np.float32 and np.array_equal(coords, np.asarray(ref_xyz, dtype=np.float32))
+    bb, aa = ae.channel_indices(names, res)
+    assert (aa >= 4).all() and ((bb >= 0) == np.isin(names, ae.BACKBONE_ATOMS)).all()
+
+
 def test_fast_npz_grid_reader_equals_numpy(tmp_path):
     """dataset.read_npz_grid (one fromfile behind the ZIP + npy headers) against np.load, incl. the fallbacks."""
     from mica_amd.dataset import read_npz_grid
