@@ -44,6 +44,8 @@ typedef struct mica_ctx mica_ctx;
 #define MICA_AF_NONE 0      /* af_features is None                                  (model.py:56)  */
 #define MICA_AF_PER_TILE 1  /* |af|.sum() < 1e-6 tested per tile = reference at batch 1 (predict.py:193,279) */
 #define MICA_AF_BATCH 2     /* tested over the whole batch, as MICA.forward does     (model.py:60)  */
+#define MICA_AF_ALWAYS 3    /* no test: every tile takes the AF3 branch - for a caller that cut one batch into several calls and
+                               evaluated the batch-wide test itself (mica_amd/engine.py does for batches beyond max_batch)      */
 
 int mica_abi_version(void);
 

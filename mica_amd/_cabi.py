@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmica_hip.so")
 
 MICA_OK = 0
 MICA_ERR_ARG, MICA_ERR_HIP, MICA_ERR_STATE, MICA_ERR_RANGE = -1, -2, -3, -4
-AF_NONE, AF_PER_TILE, AF_BATCH = 0, 1, 2
+AF_NONE, AF_PER_TILE, AF_BATCH, AF_ALWAYS = 0, 1, 2, 3
 
 _P = C.c_void_p
 _I, _L, _F = C.c_int, C.c_int64, C.c_float

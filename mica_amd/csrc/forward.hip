@@ -420,7 +420,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     if (!c->finalized) { c->err = "weights not finalized"; return MICA_ERR_STATE; }
     if (B < 1 || B > c->maxB) { c->err = "batch out of range [1, max_batch]"; return MICA_ERR_ARG; }
     if (!d_map || !o_bb || !o_ca || !o_aa) { c->err = "null pointer argument"; return MICA_ERR_ARG; }
-    if (af_mode != MICA_AF_NONE && af_mode != MICA_AF_PER_TILE && af_mode != MICA_AF_BATCH) { c->err = "bad af_mode"; return MICA_ERR_ARG; }
+    if (af_mode < MICA_AF_NONE || af_mode > MICA_AF_ALWAYS) { c->err = "bad af_mode"; return MICA_ERR_ARG; }
     HIPC(c, hipSetDevice(c->device));
     const int V = c->V;
     c->ev_used = 0;
@@ -429,6 +429,8 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     std::vector<char> use(B, 0);
     if (force_use) {
         for (int b = 0; b < B; ++b) use[b] = force_use[b];
+    } else if (d_af && af_mode == MICA_AF_ALWAYS) {
+        for (int b = 0; b < B; ++b) use[b] = 1;        // the caller evaluated the test itself (a batch cut into several calls)
     } else if (d_af && af_mode != MICA_AF_NONE) {
         // is_af_zero = af.abs().sum() < 1e-6  (model.py:60): device reduction, one small D2H per call
         HIPC(c, hipMemsetAsync(c->v_abs, 0, sizeof(float) * B, st));

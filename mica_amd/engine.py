@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _cabi
-from ._cabi import MicaHipError, AF_NONE, AF_PER_TILE, AF_BATCH  # noqa: F401
+from ._cabi import MicaHipError, AF_NONE, AF_PER_TILE, AF_BATCH, AF_ALWAYS  # noqa: F401
 
 
 def _ptr(t):
@@ -107,11 +107,16 @@ class Engine:
             warnings.warn(f"{what}: activations of a tile exceeded {60000 / self.LOW_SCALE_WARN:.0f}; it was computed at activation "
                           f"scale {sc} where the whole-network error can exceed 1e-4 (up to ~2e-4 measured)", RuntimeWarning, stacklevel=3)
 
-    def _check_batch_mode(self, n: int, af, af_mode: int):
-        """The batch-wide AF3 test (models/model.py:60) is a property of ONE forward call: a batch larger than the engine's
-        max_batch would be cut into several calls and silently become a different test."""
-        if af is not None and af_mode == AF_BATCH and n > self.max_batch:
-            raise MicaHipError(f"AF_BATCH over {n} tiles needs an engine with max_batch >= {n} (this one: {self.max_batch})")
+    def _batch_mode(self, n: int, af, af_mode: int):
+        """-> (af, af_mode) for the per-call chunks.  The batch-wide AF3 test (models/model.py:60: af.abs().sum() < 1e-6) is a
+        property of ONE forward call of the reference; a batch beyond max_batch is cut into several library calls, so the test is
+        evaluated here over the whole batch and the chunks are told its outcome (AF_ALWAYS, or no AF3 input at all)."""
+        if af is None:
+            return None, AF_NONE
+        if af_mode == AF_BATCH and n > self.max_batch:
+            per_tile = af.abs().sum(dim=tuple(range(1, af.dim())), dtype=torch.float32)
+            return (None, AF_NONE) if float(per_tile.double().sum()) < 1e-6 else (af, AF_ALWAYS)
+        return af, af_mode
 
     def _cubic(self, what):
         if self.tile_size is None:
@@ -128,7 +133,7 @@ class Engine:
             af = _f32c(af, "af_features")
             if tuple(af.shape) != (B, 24, *dims):
                 raise MicaHipError(f"af_features must be [B,24,{dims[0]},{dims[1]},{dims[2]}], got {tuple(af.shape)}")
-        self._check_batch_mode(B, af, af_mode)
+        af, af_mode = self._batch_mode(B, af, af_mode)
         bb = torch.empty((B, 4, *dims), dtype=torch.float32, device=self.device)
         ca = torch.empty_like(bb)
         aa = torch.empty((B, 21, *dims), dtype=torch.float32, device=self.device)
@@ -137,7 +142,7 @@ class Engine:
             b1 = min(B, b0 + self.max_batch)
             self._check_forward(self.lib.mica_forward_logits(
                 self._h, _ptr(exp_map[b0:b1]), _ptr(af[b0:b1]) if af is not None else None, b1 - b0,
-                af_mode if af is not None else AF_NONE, _ptr(bb[b0:b1]), _ptr(ca[b0:b1]), _ptr(aa[b0:b1]), self._stream()),
+                af_mode, _ptr(bb[b0:b1]), _ptr(ca[b0:b1]), _ptr(aa[b0:b1]), self._stream()),
                 "mica_forward_logits")
         return bb, ca, aa
 
@@ -148,7 +153,7 @@ class Engine:
         map_tiles = _f32c(map_tiles, "map_tiles").view(T, 1, S, S, S)
         if af_tiles is not None:
             af_tiles = _f32c(af_tiles, "af_tiles").view(T, 24, S, S, S)
-        self._check_batch_mode(T, af_tiles, af_mode)
+        af_tiles, af_mode = self._batch_mode(T, af_tiles, af_mode)
         if out is None:
             out = (torch.empty((T, S, S, S), dtype=torch.float32, device=self.device),
                    torch.empty((T, S, S, S), dtype=torch.float32, device=self.device),
@@ -160,7 +165,7 @@ class Engine:
             b1 = min(T, b0 + self.max_batch)
             self._check_forward(self.lib.mica_forward_tiles(
                 self._h, _ptr(map_tiles[b0:b1]), _ptr(af_tiles[b0:b1]) if af_tiles is not None else None, b1 - b0,
-                af_mode if af_tiles is not None else AF_NONE, _ptr(bbp[b0:b1]), _ptr(cap[b0:b1]), _ptr(aap[b0:b1]),
+                af_mode, _ptr(bbp[b0:b1]), _ptr(cap[b0:b1]), _ptr(aap[b0:b1]),
                 _ptr(pred[b0:b1]), self._stream()), "mica_forward_tiles")
         return out
 
@@ -172,7 +177,7 @@ class Engine:
         map_tiles = _f32c(map_tiles, "map_tiles").view(T, 1, S, S, S)
         if af_tiles is not None:
             af_tiles = _f32c(af_tiles, "af_tiles").view(T, 24, S, S, S)
-        self._check_batch_mode(T, af_tiles, af_mode)
+        af_tiles, af_mode = self._batch_mode(T, af_tiles, af_mode)
         if rec.dtype != torch.float32 or not rec.is_cuda or not rec.is_contiguous() or tuple(rec.shape) != (T, 23, S, S, S):
             raise MicaHipError(f"rec must be a contiguous float32 CUDA(HIP) tensor [{T},23,{S},{S},{S}]")
         self._begin_forward()
@@ -180,7 +185,7 @@ class Engine:
             b1 = min(T, b0 + self.max_batch)
             self._check_forward(self.lib.mica_forward_records(
                 self._h, _ptr(map_tiles[b0:b1]), _ptr(af_tiles[b0:b1]) if af_tiles is not None else None, b1 - b0,
-                af_mode if af_tiles is not None else AF_NONE, _ptr(rec[b0:b1]), self._stream()), "mica_forward_records")
+                af_mode, _ptr(rec[b0:b1]), self._stream()), "mica_forward_records")
         return rec
 
     def postprocess(self, bb, ca, aa):
