@@ -111,9 +111,11 @@ def _worker(rank, world, port, T, B, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("T,B,world", [(13, 4, 2), (8, 4, 2), (3, 4, 2), (29, 4, 4), (5, 2, 3)])
+@pytest.mark.parametrize("T,B,world", [(13, 4, 2), (8, 4, 2), (3, 4, 2), (29, 4, 4), (5, 2, 3), (133, 8, 8)])
 def test_sharded_records_gloo_world2(tmp_path, T, B, world):
-    """world 2 ... 4: more ranks than batches in the last round, ranks that get no batch at all ((3, 4, 2), (5, 2, 3))."""
+    """world 2 ... 4: more ranks than batches in the last round, ranks that get no batch at all ((3, 4, 2), (5, 2, 3)); (133, 8, 8) is
+    the rank count and batch size of BASELINE.json's configs[2] with a tenth of the default tiling's 1331 windows (ragged last batch,
+    a last round that only five of the eight ranks take part in)."""
     port = 29500 + (os.getpid() + 7 * T + world) % 2000
     out = str(tmp_path / "got.pt")
     mp.spawn(_worker, args=(world, port, T, B, out), nprocs=world, join=True)
