@@ -30,6 +30,9 @@
 // the bytes in flight.  Also tried: padding the stage planes and XOR-swizzling the epilogue tile against the 20 % LDS bank-conflict
 // share the counters show (under a 32-bank and under a 64-bank model of the LDS): the counter went to 40 % and the kernels 2-4 %
 // slower both times; the kernel is not LDS-bound (LDS busy 21-32 % of the cycles), so the layout stays.
+// Tried in round 4 and dropped: fetching a raw chunk pair line-wise (thread = (row, 8-channel group of the pair's 32 channels): the four
+// lanes of a quad read one 128-byte line instead of two half-used ones) - bench.py 83.24 against 83.33 / 82.76 sub-grids/s on one box: the
+// vector-memory front end is not what the kernel waits on either.
 // LDS: two 16-KB stages of [chunk-in-pair 2][plane 4 = hi/lo x channel half][128 rows] 16-byte slots (a ds_read_b128 lane
 // group covers 16 consecutive slots), refilled one pair ahead: global loads for pair p+1 are issued before the MFMAs of
 // pair p and committed to LDS after them, one barrier per pair.
