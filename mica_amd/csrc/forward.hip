@@ -123,12 +123,21 @@ namespace {
             return MICA_ERR_HIP;                                                                     \
         }                                                                                            \
     } while (0)
+// Entry of every call that launches work: the context's device becomes current, and a stale error of an EARLIER call (ours, already
+// reported through its return code, or the host program's) is dropped so that the hipGetLastError() checks below speak about this
+// call's launches only (a failed hipMalloc of a refused context used to fail the next context's mica_finalize_weights).
+#define MICA_ENTER(ctx)                                                                              \
+    do {                                                                                             \
+        HIPC(ctx, hipSetDevice((ctx)->device));                                                      \
+        (void)hipGetLastError();                                                                     \
+    } while (0)
 
 template <typename T> int dalloc(mica_ctx* c, T** p, int64_t n) {
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, (size_t)(n * (int64_t)sizeof(T)));
     if (e != hipSuccess) {
         c->err = "hipMalloc(" + std::to_string(n * (int64_t)sizeof(T)) + " B): " + hipGetErrorString(e);
+        (void)hipGetLastError();      // reported here: the runtime's sticky last-error must not fail the next call's hipGetLastError() check
         return MICA_ERR_HIP;
     }
     c->allocs.push_back(q);
@@ -421,7 +430,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
     if (B < 1 || B > c->maxB) { c->err = "batch out of range [1, max_batch]"; return MICA_ERR_ARG; }
     if (!d_map || !o_bb || !o_ca || !o_aa) { c->err = "null pointer argument"; return MICA_ERR_ARG; }
     if (af_mode < MICA_AF_NONE || af_mode > MICA_AF_ALWAYS) { c->err = "bad af_mode"; return MICA_ERR_ARG; }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     const int V = c->V;
     c->ev_used = 0;
     for (double& w : c->prof_work) w = 0;
@@ -479,7 +488,7 @@ struct Tmp {
     ~Tmp() { for (void* q : p) hipFree(q); }
     template <typename T> T* get(int64_t n) {
         void* q = nullptr;
-        if (hipMalloc(&q, (size_t)(n * (int64_t)sizeof(T))) != hipSuccess) return nullptr;
+        if (hipMalloc(&q, (size_t)(n * (int64_t)sizeof(T))) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         p.push_back(q);
         return (T*)q;
     }
@@ -655,7 +664,7 @@ int mica_get_conv_variant(const mica_ctx* c) { return c ? c->f43_mode : MICA_ERR
 int mica_finalize_weights(mica_ctx* c) {
     if (!c) return MICA_ERR_ARG;
     if (c->finalized) { c->err = "already finalized"; return MICA_ERR_STATE; }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     int r;
     const std::string ip = "input_processing.";
     // stem: [32][1][k][k][k] x4 -> [conv][tap][32]
@@ -761,7 +770,7 @@ int mica_postprocess(mica_ctx* c, const float* d_bb, const float* d_ca, const fl
                      float* d_ca_prob, float* d_aa_prob, float* d_aa_pred, void* stream) {
     if (!c) return MICA_ERR_ARG;
     if (!d_bb || !d_ca || !d_aa || !d_bb_prob || !d_ca_prob || !d_aa_prob || !d_aa_pred || batch < 1) { c->err = "mica_postprocess: bad argument"; return MICA_ERR_ARG; }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     launch_postprocess(d_bb, d_ca, d_aa, batch, c->V, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, c->V, (int64_t)20 * c->V, (hipStream_t)stream);
     HIPC(c, hipGetLastError());
     return MICA_OK;
@@ -825,7 +834,7 @@ int mica_gather_tiles(mica_ctx* c, const float* d_vol, int channels, int64_t n0,
     if (!c) return MICA_ERR_ARG;
     int r = check_tiling(c, d_vol, d_tiles, channels, n0, n1, n2, grid, pad, first, count);
     if (r || count == 0) return r;
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     launch_gather_tiles(d_vol, channels, n0, n1, n2, grid, pad, first, count, d_tiles, (hipStream_t)stream);
     HIPC(c, hipGetLastError());
     return MICA_OK;
@@ -836,7 +845,7 @@ int mica_gather_tiles_u8(mica_ctx* c, const uint8_t* d_vol, int channels, int64_
     if (!c) return MICA_ERR_ARG;
     int r = check_tiling(c, d_vol, d_tiles, channels, n0, n1, n2, grid, pad, first, count);
     if (r || count == 0) return r;
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     launch_gather_tiles_u8(d_vol, channels, n0, n1, n2, grid, pad, first, count, d_tiles, (hipStream_t)stream);
     HIPC(c, hipGetLastError());
     return MICA_OK;
@@ -847,7 +856,7 @@ int mica_stitch_tiles(mica_ctx* c, const float* d_tiles, int channels, int64_t n
     if (!c) return MICA_ERR_ARG;
     int r = check_tiling(c, d_tiles, d_vol, channels, n0, n1, n2, grid, pad, first, count);
     if (r || count == 0) return r;
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     launch_stitch_tiles(d_tiles, channels, n0, n1, n2, grid, pad, first, count, d_vol, (hipStream_t)stream);
     HIPC(c, hipGetLastError());
     return MICA_OK;
@@ -864,7 +873,7 @@ int mica_normalise_map_np(mica_ctx* c, float* d_vol, int64_t n, int map_type, in
         c->err = "mica_normalise_map: bad argument";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     char buf[256] = {0};
     int r = normalise_map_device(d_vol, n, map_type, numpy_rules, h_stats, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
@@ -884,7 +893,7 @@ int mica_zoom_cubic_typed(mica_ctx* c, const float* d_in, int64_t n0, int64_t n1
         c->err = "mica_zoom_cubic: bad argument";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     char buf[256] = {0};
     int r = zoom_cubic_device(d_in, n0, n1, n2, o0, o1, o2, map_type, d_out, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
@@ -904,7 +913,7 @@ int mica_rasterise_atoms(mica_ctx* c, const float* d_xyz, const int32_t* d_bb, c
         c->err = "mica_rasterise_atoms: bad argument";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     char buf[256] = {0};
     int r = rasterise_atoms_device(d_xyz, d_bb, d_aa, n_atoms, h_origin, nz, ny, nx, d_vol, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
@@ -918,7 +927,7 @@ int mica_threshold_points(mica_ctx* c, const float* d_vol, int64_t n, float thr,
         c->err = "mica_threshold_points: bad argument";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     char buf[256] = {0};
     int r = threshold_points_device(d_vol, n, thr, d_idx, capacity, h_count, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
@@ -932,7 +941,7 @@ int mica_gather_values(mica_ctx* c, const float* d_vol, int channels, int64_t nv
         c->err = "mica_gather_values: bad argument";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     char buf[256] = {0};
     int r = gather_values_device(d_vol, channels, nvox, d_idx, n, d_out, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
@@ -947,7 +956,7 @@ int mica_refine_candidates(mica_ctx* c, const float* d_ca, const float* d_aa, in
         c->err = "mica_refine_candidates: bad argument";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     char buf[256] = {0};
     int r = refine_candidates_device(d_ca, d_aa, (int)n0, (int)n1, (int)n2, d_cand, n, d_coord, d_aa_out, d_ok, (hipStream_t)stream, buf,
                                      sizeof(buf));
@@ -958,7 +967,7 @@ int mica_refine_candidates(mica_ctx* c, const float* d_ca, const float* d_aa, in
 int mica_segment_sums(mica_ctx* c, const float* d_vals, const int64_t* d_seg_off, int64_t nseg, float* d_sums, void* stream) {
     if (!c) return MICA_ERR_ARG;
     if (nseg < 0 || (nseg > 0 && (!d_vals || !d_seg_off || !d_sums))) { c->err = "mica_segment_sums: bad argument"; return MICA_ERR_ARG; }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     char buf[256] = {0};
     int r = segment_sums_device(d_vals, d_seg_off, nseg, d_sums, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
@@ -973,7 +982,7 @@ int mica_nms_points(mica_ctx* c, const int32_t* d_pts, int64_t n, int64_t n0, in
         c->err = "mica_nms_points: bad argument";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     char buf[256] = {0};
     int r = nms_points_device(d_pts, n, (int)n0, (int)n1, (int)n2, radius, d_keep, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
@@ -992,7 +1001,7 @@ int mica_neighbour_matrix_np(mica_ctx* c, const double* d_cands, int64_t n, cons
         c->err = "mica_neighbour_matrix: bad argument";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     char buf[256] = {0};
     int r = neighbour_matrix_device(d_cands, n, d_bb, (int)n0, (int)n1, (int)n2, d_dis, d_mat, numpy_rules, (hipStream_t)stream, buf, sizeof(buf));
     if (r) c->err = buf;
@@ -1014,7 +1023,7 @@ int mica_op_conv3d_variant(mica_ctx* c, const float* d_x, int batch, int cin, in
         return MICA_ERR_ARG;
     }
     const bool f43 = variant == 1;
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
     const int V = d * h * w, cp = pad16(cin), nt = k * k * k;
     const bool wino = (k == 3);
@@ -1074,7 +1083,7 @@ int mica_op_norm_conv1_conv3_variant(mica_ctx* c, const float* d_x, int batch, i
         c->err = "mica_op_norm_conv1_conv3: bad argument (cin a power of two in [16,512], cmid in {64,128,256}, cout a multiple of 32)";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
     const Dims dm{d, h, w};
     const int V = d * h * w;
@@ -1134,7 +1143,7 @@ int mica_op_norm_conv1_conv3_variant(mica_ctx* c, const float* d_x, int batch, i
 int mica_op_instnorm_relu(mica_ctx* c, const float* d_x, int batch, int ch, int d, int h, int w, float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
     if (!d_x || !d_y || batch < 1 || !pow2_8_512(ch) || d < 1 || h < 1 || w < 1) { c->err = "mica_op_instnorm_relu: bad argument (C must be a power of two in [8,512])"; return MICA_ERR_ARG; }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
     const int V = d * h * w;
     Tmp t;
@@ -1161,7 +1170,7 @@ int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, 
         c->err = "mica_op_depthwise3: bad argument (C must be a multiple of 16)";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
     const int V = d * h * w;
     Tmp t;
@@ -1191,7 +1200,7 @@ int mica_op_se_depthwise(mica_ctx* c, const float* d_x, int batch, int ch, int d
         c->err = "mica_op_se_depthwise: bad argument (C a power of two in [32, 256])";
         return MICA_ERR_ARG;
     }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
     const Dims dm{d, h, w};
     const int V = d * h * w, Ch = ch / 16;
@@ -1237,7 +1246,7 @@ int mica_op_stem(mica_ctx* c, const float* d_map, int batch, int d, int h, int w
     if (!c) return MICA_ERR_ARG;
     if (!c->finalized) { c->err = "weights not finalized"; return MICA_ERR_STATE; }
     if (!d_map || !d_y || batch < 1 || d < 1 || h < 1 || w < 1) { c->err = "mica_op_stem: bad argument"; return MICA_ERR_ARG; }
-    HIPC(c, hipSetDevice(c->device));
+    MICA_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
     const int V = d * h * w;
     Tmp t;
