@@ -3,10 +3,28 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/mica_hip.h"
 
 namespace mica {
+
+// Once-per-device initialisation of a launcher (dynamic-LDS limit of its kernels, CU count) that holds when several host threads drive
+// different contexts ("different ctxs are independent", include/mica_hip.h): a device's flag is published only AFTER `init(dev)` has
+// run, so no thread can launch with a limit that is not set yet or read a CU count that is not written yet; two threads running
+// `init` at the same time is harmless (hipFuncSetAttribute and the values stored are idempotent).  Returns the current device (0..63).
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    template <typename F> int run(F&& init) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) { init(0); return 0; }
+        if (!((done.load(std::memory_order_acquire) >> dev) & 1ull)) {
+            init(dev);
+            done.fetch_or(1ull << dev, std::memory_order_release);
+        }
+        return dev;
+    }
+};
 
 // ---- activation formats ----------------------------------------------------------------------
 // raw   : float  [B][V][C]              (NDHWC, V = D*H*W voxels)

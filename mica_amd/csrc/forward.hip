@@ -16,7 +16,7 @@ using namespace mica;
 
 namespace {
 
-std::string g_create_err;
+thread_local std::string g_create_err;      // mica_last_error(NULL): the calling thread's last refused mica_create
 
 struct HostTensor {
     std::vector<float> data;

@@ -15,16 +15,6 @@ namespace mica {
 
 struct Segs { int c[MAX_SRC]; int cp[MAX_SRC]; int n; };   // channel segmentation of a conv's concatenated input
 
-// "once per device" guard for hipFuncSetAttribute (one process normally drives one GPU, but an Engine per device in one
-// process must work too: the dynamic-LDS limit of a kernel is a per-device attribute)
-static bool first_use_on_device(unsigned long long& mask) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    const bool first = !(mask >> dev & 1ull);
-    mask |= 1ull << dev;
-    return first;
-}
-
 // ================================================================================================
 // Winograd geometry shared by the kernel below: dense 3x3x3 conv with Winograd F(2,3) along x.  The kernel is
 // power/MFMA-issue bound (1.25 PF of f16 MFMA measured), so the lever left is fewer MFMAs: per output pair
@@ -581,21 +571,18 @@ static int launch_conv_wino16(const ConvSrcs& s, const _Float16* wpk, int64_t wp
     const int bn = wino16_block(cout);
     int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / bn;
     size_t lds = 2 * GeoW::CH_BYTES;
-    static unsigned long long seen = 0;
+    static PerDeviceOnce once;
     static int cus_of[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev > 63) dev = 0;
-    if (first_use_on_device(seen)) {
+    const int dev = once.run([&](int dv) {
         (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)conv_wino16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipDeviceProp_t prop;
         int c = 0;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dv) == hipSuccess) c = prop.multiProcessorCount;
         if (c < 8) c = 256;
-        cus_of[dev] = c & ~7;
-    }
+        cus_of[dv] = c & ~7;
+    });
     const int cus = cus_of[dev];
     // one persistent workgroup per CU (LDS admits no more), a multiple of eight so that every XCD gets the same number
     const int items_per_b = ntx * nty * ntz * nnb, total_items = items_per_b * B;
@@ -1003,9 +990,8 @@ static void launch_depthwise_t(const float* x, int B, Dims d, int C, const float
                                const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, int ntx, int nty, hipStream_t st) {
     using Gm = DwGeo<YO, CQ>;
     const size_t lds = (3 * Gm::PLANE + 27 * Gm::DWC) * sizeof(float);
-    static unsigned long long seen = 0;
-    if (first_use_on_device(seen))
-        (void)hipFuncSetAttribute((const void*)depthwise_kernel<YO, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static PerDeviceOnce once;
+    once.run([&](int) { (void)hipFuncSetAttribute((const void*)depthwise_kernel<YO, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     dim3 grid((unsigned)(ntx * nty * (C / Gm::DWC)), B);
     hipLaunchKernelGGL((depthwise_kernel<YO, CQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty);
 }

@@ -331,12 +331,8 @@ bool conv1x1_can_emit_wino(Dims d, int wino_kind) {
 template <int NCT, int WINO>
 static void launch_conv1x1_t(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
                              float* out_raw, SplitView wino, int B, Dims d, int cout, int total, SplitEnc enc, float out_ascale, hipStream_t st) {
-    static unsigned long long seen = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !(seen >> dev & 1ull)) {
-        seen |= 1ull << dev;
-        (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCT, WINO>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS);
-    }
+    static PerDeviceOnce once;
+    once.run([&](int) { (void)hipFuncSetAttribute((const void*)conv1x1_kernel<NCT, WINO>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS); });
     const int V = d.D * d.H * d.W;
     dim3 grid((V + C1_ROWS - 1) / C1_ROWS, B);
     int tab_stride = 0;                                   // channels of the widest raw source (multiple of 16, <= 512)

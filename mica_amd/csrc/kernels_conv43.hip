@@ -563,20 +563,16 @@ int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstri
 #else
     const size_t lds = 2 * Geo43::CH_BYTES;          // two slab buffers
 #endif
-    static unsigned long long seen = 0;
+    static PerDeviceOnce once;
     static int cus_of[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev > 63) dev = 0;
-    if (!(seen >> dev & 1ull)) {
-        seen |= 1ull << dev;
+    const int dev = once.run([&](int dv) {
         (void)hipFuncSetAttribute((const void*)conv_wino43_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipDeviceProp_t prop;
         int c = 0;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dv) == hipSuccess) c = prop.multiProcessorCount;
         if (c < 8) c = 256;
-        cus_of[dev] = c & ~7;
-    }
+        cus_of[dv] = c & ~7;
+    });
     const int cus = cus_of[dev];
     const int items_per_b = ntx * nty * ntz * nnb, total_items = items_per_b * B;
     const int nwg = total_items >= cus ? cus : ((total_items + 7) / 8) * 8;
