@@ -10,10 +10,13 @@ from .weights import param_shapes
 
 
 class MICA:
-    def __init__(self, base_filters: int = 64, dropout_schedule=None, max_batch: int = 8):
+    def __init__(self, base_filters: int = 64, dropout_schedule=None, max_batch: int = 8, max_cached_shapes: int = 4):
+        """max_cached_shapes: engines (one per tile shape, each holding its own workspace: 37 GB at 8 tiles of 64^3) kept alive;
+        the least recently used one is closed when another shape arrives."""
         if base_filters != 64:
             raise MicaHipError("only base_filters=64 (the reference default, model.py:261) is built")
         self.max_batch = max_batch
+        self.max_cached_shapes = max(1, int(max_cached_shapes))
         self._sd = None
         self._engines = {}
         self.device = None
@@ -56,7 +59,11 @@ class MICA:
         if self._sd is None:
             raise MicaHipError("MICA: load_state_dict() first (no trained weights ship with the package)")
         dims = tuple(int(v) for v in dims)
-        if dims not in self._engines:
+        if dims in self._engines:
+            self._engines[dims] = self._engines.pop(dims)          # most recently used last (dicts keep insertion order)
+        else:
+            while len(self._engines) >= self.max_cached_shapes:
+                self._engines.pop(next(iter(self._engines))).close()
             e = Engine(self.device or 0, max_batch=self.max_batch, tile_size=dims)
             e.load_state_dict(self._sd)
             self._engines[dims] = e
