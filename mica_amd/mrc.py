@@ -52,8 +52,16 @@ def read_mrc(path: str):
         h = f.read(1024)
         if len(h) < 1024:
             raise ValueError(f"{path}: truncated MRC header")
-        stamp = h[212]
-        end = ">" if stamp == 0x11 else "<"
+        # as mrcfile in its default (non-permissive) mode, which the reference uses (create_grids.py:108, preprocessing.py:98): a file
+        # without the map ID or with an unknown machine stamp is refused, not parsed as whatever its bytes happen to say
+        if h[208:212] != b"MAP ":
+            raise ValueError(f"{path}: map ID string 'MAP ' not found: not an MRC file, or the file is corrupt")
+        if h[212] == 0x44 and h[213] in (0x44, 0x41):
+            end = "<"
+        elif h[212] == 0x11 and h[213] == 0x11:
+            end = ">"
+        else:
+            raise ValueError(f"{path}: unrecognised machine stamp 0x{h[212]:02x} 0x{h[213]:02x}")
         ints = struct.unpack(end + "10i", h[0:40])
         cella = struct.unpack(end + "3f", h[40:52])
         cellb = struct.unpack(end + "3f", h[52:64])

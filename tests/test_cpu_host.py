@@ -36,6 +36,58 @@ def test_mrc_round_trip_and_axis_orders(tmp_path):
         mrc.read_mrc(p)
 
 
+def test_mrc_reader_against_hand_packed_mrc2014_headers(tmp_path):
+    """The reader against files packed here word by word from the MRC2014 layout (words 1-10 nx ny nz mode n[xyz]start m[xyz], 11-16
+    cell, 17-19 mapc mapr maps, 20-22 dmin dmax dmean, 23 ispg, 24 nsymbt, 50-52 origin, 53 'MAP ', 54 machine stamp, 55 rms), i.e.
+    independent of write_mrc: a big-endian int16 file with an extended header and permuted axes, a little-endian uint16 file with the
+    0x44 0x41 stamp, sampling m[xyz] != n[xyz]; files without the map ID or with an unknown stamp are refused as mrcfile refuses them
+    in its default mode (create_grids.py:108).  mrcfile itself is absent here: header semantics stay 'parity unpinned'."""
+    import struct
+    nx, ny, nz = 4, 3, 2
+    vals = np.arange(nx * ny * nz, dtype=np.int16).reshape(nz, ny, nx) * 7 - 30
+
+    def header(end, mode, stamp, nsymbt=0, axes=(1, 2, 3), m=(nx, ny, nz), cell=(8.0, 4.5, 3.0), origin=(1.5, -2.0, 0.25), map_id=b"MAP "):
+        h = bytearray(1024)
+        struct.pack_into(end + "10i", h, 0, nx, ny, nz, mode, -3, 5, 11, *m)
+        struct.pack_into(end + "6f", h, 40, *cell, 90.0, 90.0, 90.0)
+        struct.pack_into(end + "3i", h, 64, *axes)
+        struct.pack_into(end + "3f", h, 76, -30.0, 131.0, 50.5)
+        struct.pack_into(end + "2i", h, 88, 1, nsymbt)
+        struct.pack_into(end + "3f", h, 196, *origin)
+        h[208:212] = map_id
+        h[212:216] = bytes(stamp)
+        struct.pack_into(end + "f", h, 216, 48.3)
+        return bytes(h)
+
+    p = str(tmp_path / "be.mrc")
+    with open(p, "wb") as f:
+        f.write(header(">", 1, (0x11, 0x11, 0, 0), nsymbt=80, axes=(2, 1, 3), m=(8, 6, 2)))
+        f.write(b"\x5a" * 80)                                # extended header: skipped, kept in hd.extra
+        f.write(vals.astype(">i2").tobytes())
+    got, hd = mrc.read_mrc(p)
+    assert got.dtype == np.int16 and got.dtype.isnative and np.array_equal(got, vals)
+    assert (hd.nx, hd.ny, hd.nz, hd.mode, hd.nxstart, hd.nystart, hd.nzstart) == (4, 3, 2, 1, -3, 5, 11)
+    assert (hd.mapc, hd.mapr, hd.maps) == (2, 1, 3) and hd.nsymbt == 80 and hd.extra == b"\x5a" * 80
+    assert hd.voxel_size == (1.0, 0.75, 1.5) and hd.origin == (1.5, -2.0, 0.25)          # cella / m[xyz], not / n[xyz]
+    vol, off = mrc.transpose_to_xyz(got, hd)
+    rv, roff = vo.transpose_axes(vals, 2, 1, 3, [11, 5, -3])
+    assert np.array_equal(vol, rv) and off == roff
+
+    p2 = str(tmp_path / "le.mrc")
+    u = (vals.astype(np.int32) + 40000).astype(np.uint16)
+    with open(p2, "wb") as f:
+        f.write(header("<", 6, (0x44, 0x41, 0, 0)))
+        f.write(u.astype("<u2").tobytes())
+    got, hd = mrc.read_mrc(p2)
+    assert got.dtype == np.uint16 and np.array_equal(got, u) and hd.voxel_size == (2.0, 1.5, 1.5)
+
+    for bad in (header("<", 2, (0x44, 0x44, 0, 0), map_id=b"\0\0\0\0"), header("<", 2, (0x00, 0x00, 0, 0)), header("<", 3, (0x44, 0x44, 0, 0))):
+        with open(p2, "wb") as f:
+            f.write(bad + b"\0" * 96)
+        with pytest.raises(ValueError):
+            mrc.read_mrc(p2)
+
+
 def _write_tiles(root, shape, with_af):
     vol = synth_density(shape, 3)
     tiles, idx = vo.tile_volume(vol, 48, 8)
