@@ -6,7 +6,7 @@ residue's amino-acid channel, backbone atoms also their own (:283-298).
 
 The reference parses the PDB with Bio.PDB.PDBParser (:52, :269); Bio is not installed here, so `read_pdb_atoms` is a
 fixed-column reader of the records PDBIO writes (the file is produced by the reference's own dock_in_map.py:698):
-ATOM records of every MODEL, coordinates kept as float32 like Bio's; HETATM records carry a non-blank hetero flag and
+ATOM records of every model (counted as Bio counts them: one per MODEL record, implicit ones outside), coordinates kept as float32 like Bio's; HETATM records carry a non-blank hetero flag and
 are skipped like :277 does; of alternate locations the highest occupancy wins (what iterating a Bio residue yields);
 an atom name repeated with the same altloc is ignored after its first occurrence (Bio's PERMISSIVE behaviour).
 """
@@ -25,18 +25,24 @@ def read_pdb_atoms(path: str):
     """-> (coords float32[n,3], atom_names list[str], res_names list[str]) for the atoms create_AF3_encodings visits."""
     chosen = {}          # (model, chain, resseq, icode, atom name) -> [occupancy, altloc, coord, resname]
     order = []
-    model = 0
+    model, model_open = -1, False
     with open(path, "r") as f:
         for line in f:
             rec = line[0:6]
+            # models as Bio's parser counts them: every MODEL record opens a new one whatever serial it carries, ENDMDL closes it, and
+            # an atom outside any model opens one implicitly - atoms of different models never replace each other
             if rec == "MODEL ":
-                try:
-                    model = int(line[10:14])
-                except ValueError:
-                    model += 1
+                model += 1
+                model_open = True
+                continue
+            if rec == "ENDMDL":
+                model_open = False
                 continue
             if rec != "ATOM  ":
                 continue                                   # HETATM: hetero flag 'H_xxx' / 'W' -> not ' ' (:277)
+            if not model_open:
+                model += 1
+                model_open = True
             name = line[12:16].strip()
             altloc = line[16]
             resname = line[17:20].strip()

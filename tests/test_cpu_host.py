@@ -269,6 +269,11 @@ def test_af3_pdb_reader_and_oracle_rasteriser(tmp_path):
     assert coords.dtype == np.float32 and np.allclose(coords[2], [6, 6, 6])
     bb, aa = ae.channel_indices(names, res)
     assert bb.tolist() == [1, 0, -1, 3, -1] and aa.tolist() == [4, 4, 4, -1, 4 + 9]
+    # models: two MODEL records with the same serial, then atoms behind ENDMDL without a MODEL record - three models, the same
+    # (chain, residue, atom) in each of them is kept three times
+    ca = _pdb_line("ATOM", 1, "CA", " ", "GLY", "A", 1, 1.0, 1.0, 1.0)
+    pdb.write_text("MODEL        1\n" + ca + "ENDMDL\nMODEL        1\n" + ca + "ENDMDL\n" + ca + "END\n")
+    assert len(ae.read_pdb_atoms(str(pdb))[1]) == 3
 
     shape = (9, 9, 9)
     vol = ao.rasterise_atoms(coords, names, res, (0.0, 0.0, 0.0), shape)
