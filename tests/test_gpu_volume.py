@@ -602,3 +602,35 @@ def test_uint8_encoding_volume_equals_float32(eng):
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert T == 8
+
+
+def test_the_ctypes_stub_printed_in_integration_md_runs_as_printed(weights):
+    """INTEGRATION.md section 3 shows a non-Python host how to bind the C ABI; the block is executed here verbatim (with the tensors it
+    names defined around it) and its outputs compared with the Engine's, so the document cannot drift from the library."""
+    import re
+    from mica_amd.engine import AF_PER_TILE, Engine
+    from mica_amd.synth import synth_af, synth_density
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"A ctypes stub.*?```python\n(.*?)```", text, re.S)
+    assert m, "the ctypes stub of section 3 is gone"
+    code = m.group(1)
+    assert 'C.CDLL("mica_amd/lib/libmica_hip.so")' in code
+    code = code.replace('"mica_amd/lib/libmica_hip.so"', repr(os.path.join(root, "mica_amd", "lib", "libmica_hip.so")))
+    S, B = 64, 2
+    x = torch.from_numpy(synth_density((B, 1, S, S, S), 5)).cuda()
+    af = torch.stack([torch.from_numpy(synth_af((S, S, S), 5, 0.01)), torch.zeros(24, S, S, S)]).cuda()
+    ns = {"state_dict": {k: torch.from_numpy(v) for k, v in weights.items()}, "x": x, "af": af, "B": B,
+          "bb_prob": torch.empty(B, S, S, S, device="cuda"), "ca_prob": torch.empty(B, S, S, S, device="cuda"),
+          "aa_prob": torch.empty(B, 20, S, S, S, device="cuda"), "aa_pred": torch.empty(B, S, S, S, device="cuda"),
+          "rec": torch.empty(B, 23, S, S, S, device="cuda")}
+    exec(compile(code, "INTEGRATION.md#3", "exec"), ns)           # noqa: S102
+    torch.cuda.synchronize()
+    assert ns["rc"] == 0
+    e = Engine(0, max_batch=8, tile_size=S)
+    e.load_state_dict(weights)
+    bb, ca, aa, pred = e.forward_tiles(x.view(B, S, S, S), af, af_mode=AF_PER_TILE)
+    assert torch.equal(ns["bb_prob"], bb) and torch.equal(ns["ca_prob"], ca) and torch.equal(ns["aa_prob"], aa) and torch.equal(ns["aa_pred"], pred)
+    rec = ns["rec"]
+    assert torch.equal(rec[:, 0], bb) and torch.equal(rec[:, 1], ca) and torch.equal(rec[:, 2], pred) and torch.equal(rec[:, 3:], aa)
+    e.close()
