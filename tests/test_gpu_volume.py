@@ -634,3 +634,27 @@ def test_the_ctypes_stub_printed_in_integration_md_runs_as_printed(weights):
     rec = ns["rec"]
     assert torch.equal(rec[:, 0], bb) and torch.equal(rec[:, 1], ca) and torch.equal(rec[:, 2], pred) and torch.equal(rec[:, 3:], aa)
     e.close()
+
+
+def test_the_disk_free_snippet_printed_in_integration_md_runs_as_printed(tmp_path, weights):
+    """INTEGRATION.md section 2's disk-free replacement of Solver.getData / nnPred, executed verbatim on a small map written here."""
+    import re
+    import types
+    from mica_amd import mrc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"Disk-free variant.*?```python\n(.*?)```", text, re.S)
+    assert m, "the disk-free snippet of section 2 is gone"
+    data = synth_density((50, 60, 70), 21)                               # [nz, ny, nx]
+    mrc.write_mrc(str(tmp_path / "n.mrc"), data, nxstart=3, nystart=-4, nzstart=9)
+    torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in weights.items()}}, str(tmp_path / "m.pth"))
+    ns = {"cfg": types.SimpleNamespace(model_path=str(tmp_path / "m.pth"), normalized_map_path=str(tmp_path / "n.mrc")),
+          "self": types.SimpleNamespace(), "af_volume_or_None": None, "torch": torch}
+    exec(compile(m.group(1), "INTEGRATION.md#2", "exec"), ns)             # noqa: S102
+    vols, me = ns["vols"], ns["self"]
+    assert me.offset == [3.0, -4.0, 9.0] and me.AAPred.shape == (70, 60, 50) and me.AAPred.dtype == np.float32
+    assert set(vols) == {"amino_acid_prediction", "amino_acid_probability", "backbone_probability", "carbon_alpha_probability"}
+    assert tuple(vols["amino_acid_probability"].shape) == (20, 70, 60, 50)
+    assert float(vols["backbone_probability"].min()) >= 0.0 and float(vols["backbone_probability"].max()) <= 1.0
+    assert np.array_equal(np.unique(me.AAPred), np.unique(me.AAPred).round()) and me.AAPred.min() >= 0 and me.AAPred.max() <= 19
+    ns["eng"].close()
