@@ -71,16 +71,18 @@ int mica_load_weight(mica_ctx* ctx, const char* name, const float* h_data, const
  * - f16 hi + lo halves of w * 2^k (k per layer: max |w| in (2048, 4096]):
  *     1x1x1 convs                 [Cin/16][hi|lo][k-half][Cout][8]
  *     3x3x3 convs, F(2,3) kernel  [Cout/bn][Cin/16][tap pair 5][Winograd position 4][unit 8][bn][8], bn = 128 / 64 / 32
- *     3x3x3 convs, F(4,3) kernel  [Cout/128][Cin/16][tap pair 5][Winograd position 6][unit 8][128][8]   (encoder.2, see
+ *     3x3x3 convs, F(4,3) kernel  [Cout/128][Cin/16][tap pair 5][Winograd position 6][unit 8][128][8]   (see
  *                                 mica_set_conv_variant); units = hi / lo x first / second tap of the pair x channel half
  *   with the Winograd weight transforms applied (the layers whose inputs carry a per-tile gate are re-packed per tile at run time).
  * Blocks until done.                                                                                                            */
 int mica_finalize_weights(mica_ctx* ctx);
 
 /* Which dense 3x3x3 convs run on the Winograd F(4,3)-along-x kernel (1.33x fewer MFMAs, ~4x the per-layer rounding error) instead
- * of F(2,3): 0 = none, 1 = the four convs of encoder.2 (models/model.py:107,115,122,142 at C = 256: 68 % of the network's FLOPs;
- * whole-network error indistinguishable from mode 0, profiles/r04_wino_network_numerics.txt) - the default, also settable through
- * the environment (MICA_F43=0|1, read by mica_create).  The variant decides how weights are packed: before mica_finalize_weights. */
+ * of F(2,3): 0 = none; 1 = the four convs of encoder.2 (models/model.py:107,115,122,142 at C = 256: 68 % of the network's FLOPs) -
+ * the default: whole-network error indistinguishable from mode 0 (profiles/r04_wino_network_numerics.txt); 2 = those and encoder.1's
+ * transition conv (128 -> 256, 6 % of the FLOPs: +0.7 % throughput, rms error +1-2 %, profiles/r04_f43_ab_bench.txt).  Also settable
+ * through the environment (MICA_F43=0|1|2, read by mica_create).  The variant decides how weights are packed: before
+ * mica_finalize_weights.                                                                                                            */
 int mica_set_conv_variant(mica_ctx* ctx, int mode);
 int mica_get_conv_variant(const mica_ctx* ctx);
 

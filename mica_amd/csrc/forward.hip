@@ -95,7 +95,8 @@ struct mica_ctx {
     int* d_err = nullptr;            // range flags, one per tile of the call (int[maxB])
     int* cur_err = nullptr;          // ... of the run of tiles forward_run is working on
     float ascale = ASCALE_DEFAULT;   // activation scale of the split encoding (common.h) every forward call starts from
-    int f43_mode = 1;                // 0: every 3^3 conv on the F(2,3) kernel; 1: encoder.2's four convs on the F(4,3) kernel (default)
+    int f43_mode = 1;                // 0: every 3^3 conv on the F(2,3) kernel; 1 (default): encoder.2's four convs on the F(4,3) kernel; 2: those and
+                                     // encoder.1's transition
     float last_scale = ASCALE_DEFAULT;   // the lowest scale a tile of the last forward call needed (forward_checked)
     int last_retries = 0;                // tiles of the last forward call that had to be repeated at a lower scale
     std::vector<char> use_af;        // per tile of the last forward_impl call: AF3 branch taken
@@ -362,8 +363,8 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
     for (int e = 0; e < 3; ++e) {
         Enc& E = c->enc[e];
         const int C = E.C, cc = C / 16, ch = C / 32;   // chunks of C and of C/2
-        // encoder.2's four 3^3 convs run on the F(4,3) kernel: every operand they read (x = c_1, x1, x2, the fusion's output) is
-        // written in that kernel's layout by its producer; no tensor is needed in both layouts
+        // encoder.2's four 3^3 convs (and, in mode 2, encoder.1's transition) run on the F(4,3) kernel: every operand they read
+        // (x = c_1, x1, x2, the fusions' outputs) is written in that kernel's layout by its producer; no tensor is needed in both layouts
         const bool f43 = E.conv1.f43, f43_next = e < 2 && c->enc[e + 1].conv1.f43;
         // ResidualDenseBlock (model.py:130-134)
         run_conv(c, E.conv1, SrcList().add(X, cc, 0, cc), c->R_a, B, st, c->v_mean, c->v_rstd);
@@ -391,7 +392,7 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         {
             // fusion (model.py:96, 101) reads the two branches raw: local = relu(IN(depthwise)), global = relu(IN(conv3)) * gates
             const Conv1Src glob = raw_src(c->R_b, C, c->v_mean3, c->v_rstd3, 1);
-            run_conv1x1(c, E.fusion, raw_src(c->R_c, C, c->v_mean, c->v_rstd, 1), &glob, view(c->S_f, cc, 0, cc), c->R_a, B, st, f43);
+            run_conv1x1(c, E.fusion, raw_src(c->R_c, C, c->v_mean, c->v_rstd, 1), &glob, view(c->S_f, cc, 0, cc), c->R_a, B, st, E.transition.f43);
         }
         // transition (model.py:141-147); c_e feeds the next encoder's 3^3 convs and the FPN's 1x1 lateral
         run_conv(c, E.transition, SrcList().add(c->S_f, cc, 0, cc), c->R_a, B, st, c->v_mean, c->v_rstd);
@@ -583,7 +584,7 @@ int mica_create_dims(int device, int max_batch, int td, int th, int tw, mica_ctx
         return MICA_ERR_HIP;
     }
     mica_ctx* c = new mica_ctx();
-    if (const char* ev = getenv("MICA_F43")) c->f43_mode = atoi(ev) != 0;      // A/B switch (0: the F(2,3) kernel everywhere)
+    if (const char* ev = getenv("MICA_F43")) { const int m = atoi(ev); c->f43_mode = m < 0 || m > 2 ? 1 : m; }      // A/B switch (0: the F(2,3) kernel everywhere)
     c->device = device;
     c->maxB = max_batch;
     c->S = tile_size;
@@ -653,7 +654,7 @@ int mica_load_weight(mica_ctx* c, const char* name, const float* h_data, const i
 
 int mica_set_conv_variant(mica_ctx* c, int mode) {
     if (!c) return MICA_ERR_ARG;
-    if (mode != 0 && mode != 1) { c->err = "mica_set_conv_variant: mode must be 0 or 1"; return MICA_ERR_ARG; }
+    if (mode < 0 || mode > 2) { c->err = "mica_set_conv_variant: mode must be 0, 1 or 2"; return MICA_ERR_ARG; }
     if (c->finalized) { c->err = "mica_set_conv_variant: weights already finalized (the variant decides how they are packed)"; return MICA_ERR_STATE; }
     c->f43_mode = mode;
     return MICA_OK;
@@ -706,16 +707,17 @@ int mica_finalize_weights(mica_ctx* c) {
         const int C = 64 << e;
         E.C = C;
         const std::string p = "encoder." + std::to_string(e) + ".";
-        // all four 3^3 convs of an encoder switch together (they share operands): encoder.2 has Cout = 128, 128, 256, 512
-        const bool f43 = c->f43_mode == 1 && e == 2;
+        // the three dense-block convs of an encoder switch together (they share operands): encoder.2 has Cout = 128, 128, 256; a
+        // transition conv is the only reader of its operand (the 1x1 fusion's output), so encoder.1's (128 -> 256) can switch alone
+        const bool f43 = c->f43_mode != 0 && e == 2, f43t = f43 || (c->f43_mode == 2 && e == 1);
         if ((r = setup_conv(c, E.conv1, p + "dense_block.conv1.0", C / 2, 3, {C}, false, 1.f, f43))) return r;
         if ((r = setup_conv(c, E.conv2, p + "dense_block.conv2.0", C / 2, 3, {C, C / 2}, false, 1.f, f43))) return r;
         if ((r = setup_conv(c, E.conv3, p + "dense_block.conv3.0", C, 3, {C, C / 2, C / 2}, false, 1.f, f43))) return r;
         if ((r = setup_gate(c, E.se, p + "dense_block.se.fc.0", p + "dense_block.se.fc.3", C, C / 16, true))) return r;
         if ((r = setup_gate(c, E.ga, p + "dual_attn.global_attn.1", p + "dual_attn.global_attn.4", C, C / 4, false))) return r;
         if ((r = setup_conv(c, E.fusion, p + "dual_attn.fusion", C, 1, {C, C}, true))) return r;
-        if ((r = setup_conv(c, E.transition, p + "transition.0", 2 * C, 3, {C}, false, 1.f, f43))) return r;
-        if (E.conv1.f43 != E.conv2.f43 || E.conv1.f43 != E.conv3.f43 || E.conv1.f43 != E.transition.f43) { c->err = "internal: mixed conv variants in an encoder"; return MICA_ERR_STATE; }
+        if ((r = setup_conv(c, E.transition, p + "transition.0", 2 * C, 3, {C}, false, 1.f, f43t))) return r;
+        if (E.conv1.f43 != E.conv2.f43 || E.conv1.f43 != E.conv3.f43) { c->err = "internal: mixed conv variants in a dense block"; return MICA_ERR_STATE; }
         const HostTensor *dw = find(c, p + "dual_attn.local_attn.0.weight"), *db = find(c, p + "dual_attn.local_attn.0.bias");
         if (!shape_is(dw, {C, 1, 3, 3, 3}) || !shape_is(db, {C})) { c->err = "depthwise weights missing or mis-shaped"; return MICA_ERR_STATE; }
         std::vector<float> wt((size_t)27 * C);

@@ -23,6 +23,8 @@ Variants of the 3^3 convs:
     f43h@big   the same with the +-1/2 points
     f43@e2     F(4,3) on all four 3^3 convs of encoder.2 (68 % of the FLOPs)
     f43s, f43s@e2   the same with the points {0, +-3/2, +-2/3, inf} of the shipped kernel (kernels_conv43.hip)
+    f43s@e2t1, f43s@e2t   encoder.2 plus the transition conv of encoder.1 / of encoder.0 and encoder.1 (the other Cout % 128 == 0 layers
+                    whose operand comes straight out of a 1x1 conv's epilogue)
 
 Criterion (tests/test_gpu_model.py): scaled error max |got - ref| / max(|ref|, rms(ref)) < 1e-4 against the reference module's
 float32 logits (tests/golden/model_S16_*.npz) AND against its float64 logits (truth64_S16_*.npz), the latter also <= 1.5x the
@@ -194,6 +196,9 @@ class Emulated:
 
     def pick(self, cin, cout, name=""):
         v = self.variant
+        if "@e2t" in v:                                   # encoder.2 and the transition of encoder.1 (@e2t1) or of encoder.0 and encoder.1 (@e2t)
+            extra = ("encoder.1.transition",) if "@e2t1" in v else ("encoder.0.transition", "encoder.1.transition")
+            return {"f43": F43, "f43h": F43H, "f43s": F43S}[v.split("@")[0]] if name.startswith(("encoder.2.",) + extra) else F23
         if "@e2" in v:                                    # all four 3^3 convs of encoder.2 (conv1, conv2, conv3, transition)
             return {"f43": F43, "f43h": F43H, "f43s": F43S}[v.split("@")[0]] if name.startswith("encoder.2.") else F23
         if "@e2c" in v:
