@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <atomic>
+#include <vector>
 
 #include "../../include/mica_hip.h"
 
@@ -182,6 +183,13 @@ int64_t fused_stats_ws_floats(int B, int tile_size);
 void launch_stem(const float* map, int B, Dims d, const float* wstem, const float* bstem, SplitView out,
                  float* out_raw, float* gap, float* ws, SplitEnc enc, hipStream_t st);
 int64_t stem_weight_floats();
+// the stem on the matrix cores (kernels_stem.hip), for tile widths that are multiples of 64
+struct StemPlan { int first[4][8]; int steps[4][8]; int records; };      // K-step records of (kernel size, residue class of x mod 8)
+void stem_mfma_plan(const float* w, std::vector<float>& wf, std::vector<int>& aoff, StemPlan& plan);
+void launch_stem_mfma_pack(const float* d_wf, int records, float wscale, _Float16* d_rec, hipStream_t st);
+bool stem_mfma_eligible(Dims d);
+int launch_stem_mfma(const float* map, int B, Dims d, const _Float16* wrec, const int* aoff, const StemPlan& plan, float wscale,
+                     const float* bstem, SplitView out, float* out_raw, float* ws, SplitEnc enc, hipStream_t st);
 // x_feat raw [B][V][64] -> split(x_feat * sigmoid(w2 . relu(W0 x + b0) + b2))
 void launch_feat_gate(const float* x, int B, int V, const float* w0, const float* b0, const float* w2,
                       const float* b2, SplitView out, SplitEnc enc, hipStream_t st);

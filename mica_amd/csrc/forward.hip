@@ -76,6 +76,11 @@ struct mica_ctx {
 
     // weights
     float *stem_w = nullptr, *stem_b = nullptr;
+    _Float16* stem_rec = nullptr;     // the stem on the matrix cores (kernels_stem.hip): packed K-step records, block offsets, plan
+    int* stem_aoff = nullptr;
+    StemPlan stem_plan{};
+    float stem_wscale = 1.f;
+    int stem_mode = 1;               // 0: the f32 VALU stem everywhere (A/B switch, MICA_STEM_MFMA=0)
     GateMLP exp_att;
     ConvLayer downsizing, feat_conv, fusion0;
     float *fg_w0 = nullptr, *fg_b0 = nullptr, *fg_w2 = nullptr, *fg_b2 = nullptr;
@@ -337,6 +342,18 @@ void make_operand(mica_ctx* c, const float* raw, int B, int C, const float* mean
     }
 }
 
+// The stem: on the matrix cores for tile widths that are multiples of 64 (kernels_stem.hip), else the f32 VALU kernel; both write the
+// split view of the 128 channels and / or the raw tensor, and the per-tile channel means (gap, nullable).
+void run_stem(mica_ctx* c, const float* d_map, int B, Dims d, SplitView out, float* out_raw, float* gap, SplitEnc enc, hipStream_t st) {
+    if (c->stem_mode != 0 && stem_mfma_eligible(d)) {
+        const int nblk = launch_stem_mfma(d_map, B, d, c->stem_rec, c->stem_aoff, c->stem_plan, c->stem_wscale, c->stem_b, out, out_raw,
+                                          gap ? c->ws : nullptr, enc, st);
+        if (gap) launch_finalize_sum(c->ws, B, nblk, 128, 1.0f / (float)(d.D * d.H * d.W), gap, st);
+        return;
+    }
+    launch_stem(d_map, B, d, c->stem_w, c->stem_b, out, out_raw, gap, c->ws, enc, st);
+}
+
 // One run of tiles that share the AF branch (model.py:56-74).  Workspace slots 0..B-1.
 int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool use_af, float* o_bb, float* o_ca,
                 float* o_aa, hipStream_t st, int slot0) {
@@ -345,7 +362,7 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
     SplitView none{nullptr, 0, 0, 0};
     c->cur_err = c->d_err + slot0;
     // ---- MultiScaleInput (model.py:43-74) ------------------------------------------------------
-    launch_stem(d_map, B, d, c->stem_w, c->stem_b, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, c->ws, SplitEnc{c->cur_err, c->ascale}, st);
+    run_stem(c, d_map, B, d, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, SplitEnc{c->cur_err, c->ascale}, st);
     if (!use_af) {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->downsizing.d_cin_scale, 128, st);
         run_conv1x1(c, c->downsizing, split_src(c->S_exp, 8, 0, 8), nullptr, view(c->S_x0, 4, 0, 4), c->R_a, B, st);
@@ -584,6 +601,7 @@ int mica_create_dims(int device, int max_batch, int td, int th, int tw, mica_ctx
         return MICA_ERR_HIP;
     }
     mica_ctx* c = new mica_ctx();
+    if (const char* ev = getenv("MICA_STEM_MFMA")) c->stem_mode = atoi(ev) != 0;
     if (const char* ev = getenv("MICA_F43")) { const int m = atoi(ev); c->f43_mode = m < 0 || m > 2 ? 1 : m; }      // A/B switch (0: the F(2,3) kernel everywhere)
     c->device = device;
     c->maxB = max_batch;
@@ -685,6 +703,18 @@ int mica_finalize_weights(mica_ctx* c) {
         }
         if ((r = upload(c, &c->stem_w, w))) return r;
         if ((r = upload(c, &c->stem_b, b))) return r;
+        // the matrix-core form of the same weights: per (kernel size, residue class of x mod 8) K-step records, f16 hi + lo of w * 2^k
+        std::vector<float> wf;
+        std::vector<int> aoff;
+        stem_mfma_plan(w.data(), wf, aoff, c->stem_plan);
+        c->stem_wscale = pick_wscale(w, 1.f);
+        float* d_wf = nullptr;
+        if ((r = upload(c, &d_wf, wf))) return r;
+        if ((r = dalloc(c, &c->stem_aoff, (int64_t)aoff.size()))) return r;
+        HIPC(c, hipMemcpy(c->stem_aoff, aoff.data(), aoff.size() * sizeof(int), hipMemcpyHostToDevice));
+        if ((r = dalloc(c, &c->stem_rec, (int64_t)c->stem_plan.records * 4 * 64 * 8))) return r;
+        launch_stem_mfma_pack(d_wf, c->stem_plan.records, c->stem_wscale, c->stem_rec, nullptr);
+        HIPC(c, hipDeviceSynchronize());
     }
     if ((r = setup_gate(c, c->exp_att, ip + "exp_attention.1", ip + "exp_attention.3", 128, 64, false))) return r;
     if ((r = setup_conv(c, c->downsizing, ip + "exp_downsizing", 64, 1, {128}, true))) return r;
@@ -1254,7 +1284,7 @@ int mica_op_stem(mica_ctx* c, const float* d_map, int batch, int d, int h, int w
     Tmp t;
     float* raw = t.get<float>((int64_t)batch * V * 128);
     if (!raw) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
-    launch_stem(d_map, batch, Dims{d, h, w}, c->stem_w, c->stem_b, SplitView{nullptr, 0, 0, 0}, raw, nullptr, nullptr, SplitEnc{nullptr, ASCALE_DEFAULT}, st);
+    run_stem(c, d_map, batch, Dims{d, h, w}, SplitView{nullptr, 0, 0, 0}, raw, nullptr, SplitEnc{nullptr, ASCALE_DEFAULT}, st);
     launch_nhwc_to_nchw(raw, batch, 128, V, d_y, st);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(st));

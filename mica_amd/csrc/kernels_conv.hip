@@ -1019,7 +1019,8 @@ int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, co
 
 // ------------------------------------------------------------------------------------------------
 // Multi-scale stem (model.py:9-14,49-51): four Conv3d(1,32,k) with k = 3,5,7,9 on the density tile.
-// Cin = 1 leaves no GEMM K dimension, so this is f32 VALU work: one LDS tile with halo 4 serves all
+// This is the f32 VALU form (tile widths that are not multiples of 64; the production width runs on the matrix cores with the
+// taps as the GEMM's K dimension, kernels_stem.hip): one LDS tile with halo 4 serves all
 // four kernels; each thread keeps 2 voxels x 32 output channels in registers and the weights arrive
 // as wave-uniform scalar loads (v_fma with an SGPR operand).  Writes the 128 channels straight in
 // split format plus per-block channel sums for the attention gate's global average pool (model.py:21).

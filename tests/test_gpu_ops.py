@@ -213,8 +213,10 @@ def test_se_block_and_depthwise_local_branch(eng, c, dims, batch):
     assert rel_err(got, ref) < 5e-5                         # two InstanceNorms deep: float32 summation-order noise is ~1e-5
 
 
-@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 16, 16), (5, 9, 33)])
+@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 16, 16), (5, 9, 33), (4, 10, 64), (3, 5, 128), (17, 9, 64)])
 def test_stem(eng, weights, dims):
+    """Widths that are multiples of 64 run on the matrix cores (kernels_stem.hip: taps as the GEMM's K dimension, split-f16 products),
+    the others on the f32 VALU kernel; ragged y / z blocks on both."""
     x = _rand((2, 1, *dims), 11, 0.0, 1.0)
     outs = []
     for i, k in enumerate((3, 5, 7, 9)):
