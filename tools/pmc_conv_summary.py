@@ -19,7 +19,7 @@ def short(n):
     m = re.search(r"conv1x1_kernelILi(\d+)E", n)
     if m:
         return "conv1x1_kernel<%s>" % m.group(1)
-    m = re.search(r"(conv_wino43_kernel|prep_wino43_kernel|conv_wino16_kernel<\d+>|conv2_kernel<[\d, ]+>|depthwise_kernel<[\d, ]+>|prep_wino_kernel|prep_kernel|prep_ncdhw_wino_kernel|stem_kernel|"
+    m = re.search(r"(conv_wino43_kernel|prep_wino43_kernel|stem_mfma_kernel|conv_wino16_kernel<\d+>|conv2_kernel<[\d, ]+>|depthwise_kernel<[\d, ]+>|prep_wino_kernel|prep_kernel|prep_ncdhw_wino_kernel|stem_kernel|"
                   r"stats_finalize_kernel|feat_gate_kernel|head_final_kernel|postprocess_kernel|gather_tiles_kernel|stitch_tiles_kernel)", n)
     return m.group(1) if m else None
 

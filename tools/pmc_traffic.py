@@ -12,7 +12,7 @@ def load(path, counter):
     return per
 
 def short(n):
-    for key in ("conv_wino43_kernel", "prep_wino43_kernel", "conv_wino16_kernel", "conv1x1_kernel", "depthwise_kernel", "prep_wino_kernel", "prep_kernel",
+    for key in ("conv_wino43_kernel", "prep_wino43_kernel", "stem_mfma_kernel", "conv_wino16_kernel", "conv1x1_kernel", "depthwise_kernel", "prep_wino_kernel", "prep_kernel",
                 "stats_kernel", "stem_kernel", "gather_tiles_kernel", "stitch_tiles_kernel", "postprocess_kernel", "head_final_kernel",
                 "hist_kernel", "finish_kernel"):
         if key in n:
