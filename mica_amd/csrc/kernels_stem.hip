@@ -18,12 +18,13 @@
 // (L1 / L2: 2.4 MB of packed records shared by every workgroup) and 48 MFMAs for its 128 voxels x 32 channels.  The waves of a SIMD
 // are classes c and c + 4: 148-158 K-steps per block on every SIMD.  Two workgroups share a CU (128 registers, 54 KB of LDS each): one's
 // tile fill and epilogue run beside the other's MFMAs, and nothing is double-buffered inside a wave.
-// Measured (bench.py, 8 tiles of 64^3 per launch, rocprofv3 kernel trace): 0.80 ms against 1.86 ms for the f32 VALU kernel it replaces
+// Measured (bench.py, 8 tiles of 64^3 per launch, rocprofv3 kernel trace): 0.73 ms against 1.86 ms for the f32 VALU kernel it replaces
 // (60 M MFMAs = 0.39 ms of issue at 2.4 GHz).  Ablations (-DMICA_STEM_NOLOOP: one K-step per kernel size; -DMICA_STEM_NOEPI: no
 // output) on the one-workgroup-per-CU version of 0.94 ms: 0.37 ms and 0.70 ms - the K loop was 0.57 ms (69 % MFMA-busy), the output
 // (1.07 GB of split records in 8-byte pieces) 0.24 ms, tile fill and launch 0.13 ms, all in sequence; pinning the weight prefetch,
 // batching the tile fill's loads, a conflict-free fragment mapping (y and y + 4 in one fragment) and all sixteen fragment reads up
-// front each changed nothing there, sharing the CU between two workgroups took it to 0.80 ms.
+// front each changed nothing there; sharing the CU between two workgroups took it to 0.80 ms, removing that version's 26 spilled registers
+// (fragment addresses hoisted out of the size loop) to 0.73 ms.
 // Used for tile widths that are multiples of 64 (the production tile); other widths take the f32 VALU kernel (kernels_conv.hip:
 // stem_kernel), which writes the same formats.
 #include "common.h"
@@ -235,10 +236,14 @@ __global__ __launch_bounds__(512, 4) void stem_mfma_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < 4; ++i) sums[t][i] = 0.f;
         }
+        // laundered per kernel size: as loop invariants the eight fragments' 64-bit output addresses are hoisted out of the size loop
+        // into registers that the K loop does not have to spare (26 spilled VGPRs; 124 and none with this)
+        int y0e = y0, z0e = z0;
+        asm volatile("" : "+s"(y0e), "+s"(z0e));
         const int gx = x0 + c + 8 * r;
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
-            const int gy = y0 + (f & 3) + 4 * yy, gz = z0 + (f >> 2);
+            const int gy = y0e + (f & 3) + 4 * yy, gz = z0e + (f >> 2);
 #ifdef MICA_STEM_NOEPI
             if (gy < d.H && gz < 0) {                      // ablation: no output
 #else
