@@ -84,22 +84,24 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ x,
 // Merge of the P partials f32 [B][P][C][3] = (count, mean, M2) per channel, in f64 and in a fixed order.  One block = 4
 // channels x 64 slot lanes: for a given slot the 4 channels are 48 contiguous bytes (one block per channel read its
 // 12-byte triples at a stride of C * 12 bytes: 64-B sectors for 12 useful bytes).
+template <int CL>      // channels per block (CL x 256 / CL slot lanes): per slot the block reads CL * 12 contiguous bytes
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ ws, int nblk, int C, float eps,
                                                              float* __restrict__ mean, float* __restrict__ rstd,
                                                              const float* __restrict__ gate) {
     __shared__ double sn[256], sm[256], sq[256];
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int cl = tid & 3, sl = tid >> 2, c = blockIdx.x * 4 + cl;
+    constexpr int SL = 256 / CL;
+    const int cl = tid % CL, sl = tid / CL, c = blockIdx.x * CL + cl;
     double n = 0, m = 0, q = 0;
     if (c < C)
         // eight partials are fetched before they are merged: the merge chain is sequential (fixed order), and with one load per
         // iteration the kernel spent its time in 64 dependent global-load latencies (47 -> 30 us; the rest is the traffic itself:
         // up to 200 MB of partials per launch)
-        for (int k0 = sl; k0 < nblk; k0 += 64 * 8) {
+        for (int k0 = sl; k0 < nblk; k0 += SL * 8) {
             float pn[8], pm[8], pq[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int k = k0 + 64 * u;
+                const int k = k0 + SL * u;
                 const float* w = ws + (((int64_t)b * nblk + (k < nblk ? k : k0)) * C + c) * 3;
                 pn[u] = k < nblk ? w[0] : 0.f; pm[u] = w[1]; pq[u] = w[2];
             }
@@ -116,9 +118,9 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
         }
     sn[tid] = n; sm[tid] = m; sq[tid] = q;
     __syncthreads();
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = SL / 2; off > 0; off >>= 1) {
         if (sl < off) {
-            const int o = tid + off * 4;
+            const int o = tid + off * CL;
             double nb = sn[o], mb = sm[o], qb = sq[o];
             double na = sn[tid], ma = sm[tid], qa = sq[tid];
             if (nb > 0) {
@@ -143,7 +145,12 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
 
 int64_t stats_ws_floats(int B, int C) { return (int64_t)B * RED_BLOCKS * C * 3; }
 void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, float* mean, float* rstd, hipStream_t st, const float* gate) {
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd, gate);
+    // channels per block by layer width (batch 8: C = 512 -> 16, C = 128 / 256 -> 8, narrower -> 4): wider blocks read longer contiguous
+    // runs per slot (C = 512: 132 -> 53 us, 256: 68 -> 35, 128: 33 -> 28) but give every thread a longer sequential merge chain and the
+    // chip fewer blocks (16 channels at C = 128: 48 us; one channel per block at C <= 64: 19-35 us against 17-19)
+    if ((int64_t)C * B >= 4096) hipLaunchKernelGGL(stats_finalize_kernel<16>, dim3((C + 15) / 16, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd, gate);
+    else if ((int64_t)C * B >= 1024) hipLaunchKernelGGL(stats_finalize_kernel<8>, dim3((C + 7) / 8, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd, gate);
+    else hipLaunchKernelGGL(stats_finalize_kernel<4>, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd, gate);
 }
 // fused statistics: conv_wino writes 4 partials per 16x4x4 output tile (8 for Cout = 32), depthwise one per block
 int64_t fused_stats_ws_floats(int B, int S) {
@@ -162,7 +169,7 @@ void launch_stats(const float* x, int B, int V, int C, float eps, float* mean, f
     int G = C / 8, SUB = 256 / G;
     int nblk = pick_blocks(V, SUB * 8, RED_BLOCKS);
     hipLaunchKernelGGL(stats_kernel, dim3(nblk, B), dim3(256), 3 * 256 * 8 * sizeof(float), st, x, V, C, ws);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd, (const float*)nullptr);
+    hipLaunchKernelGGL(stats_finalize_kernel<4>, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, nblk, C, eps, mean, rstd, (const float*)nullptr);
 }
 
 __global__ __launch_bounds__(256) void finalize_sum_kernel(const float* __restrict__ ws, int nblocks, int C, float inv,
