@@ -145,11 +145,12 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
 
 int64_t stats_ws_floats(int B, int C) { return (int64_t)B * RED_BLOCKS * C * 3; }
 void launch_stats_finalize(const float* ws, int B, int P, int C, float eps, float* mean, float* rstd, hipStream_t st, const float* gate) {
-    // channels per block by layer width (batch 8: C = 512 -> 16, C = 128 / 256 -> 8, narrower -> 4): wider blocks read longer contiguous
+    // channels per block by layer width ALONE (C = 512 -> 16, C = 128 / 256 -> 8, narrower -> 4; the call's batch must not enter: the
+    // partition decides the merge order, and a tile's numbers do not depend on its batch): wider blocks read longer contiguous
     // runs per slot (C = 512: 132 -> 53 us, 256: 68 -> 35, 128: 33 -> 28) but give every thread a longer sequential merge chain and the
     // chip fewer blocks (16 channels at C = 128: 48 us; one channel per block at C <= 64: 19-35 us against 17-19)
-    if ((int64_t)C * B >= 4096) hipLaunchKernelGGL(stats_finalize_kernel<16>, dim3((C + 15) / 16, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd, gate);
-    else if ((int64_t)C * B >= 1024) hipLaunchKernelGGL(stats_finalize_kernel<8>, dim3((C + 7) / 8, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd, gate);
+    if (C >= 512) hipLaunchKernelGGL(stats_finalize_kernel<16>, dim3((C + 15) / 16, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd, gate);
+    else if (C >= 128) hipLaunchKernelGGL(stats_finalize_kernel<8>, dim3((C + 7) / 8, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd, gate);
     else hipLaunchKernelGGL(stats_finalize_kernel<4>, dim3((C + 3) / 4, B), dim3(256), 0, st, ws, P, C, eps, mean, rstd, gate);
 }
 // fused statistics: conv_wino writes 4 partials per 16x4x4 output tile (8 for Cout = 32), depthwise one per block
