@@ -10,21 +10,21 @@
 //   * the weights are packed per class: W[c][(kz, ky, delta)][i] = w[kz][ky][kx = 8 delta + i - c + R] or 0 (R = k / 2).  A class
 //     needs one or two blocks per (kz, ky) (k = 9: always two; k = 7: one for c = 3, 4; k = 5: one for c = 2..5; k = 3: one for
 //     c = 1..6), so 50-56 % of the K slots carry a tap.
-// MFMA roles: A = weights (16 channels x 32 K), B = im2col (32 K x 16 voxels), D[channel][voxel]: a lane ends up with 4 consecutive
-// channels of one voxel - 8-byte pieces of the split records, 16-byte pieces of the raw output.
+// MFMA roles: A = weights (16 channels x 32 K), B = im2col (32 K x 16 voxels), D[channel][voxel]: with the rows of the two channel
+// tiles interleaved in the packing a lane ends up with 8 consecutive channels of one voxel - 16-byte pieces of the split records.
 //
 // Workgroup = 8 waves (one per class) x a 64(x) x 8(y) x 2(z) block of outputs; the input tile with halo 4 (x: the aligned range
 // -8 .. 71) sits in LDS as f16 hi and lo planes (2 x 25 KB).  Per K-step of 32 slots a wave issues 16 ds_read_b128, 4 weight loads
 // (L1 / L2: 2.4 MB of packed records shared by every workgroup) and 48 MFMAs for its 128 voxels x 32 channels.  The waves of a SIMD
 // are classes c and c + 4: 148-158 K-steps per block on every SIMD.  Two workgroups share a CU (128 registers, 54 KB of LDS each): one's
 // tile fill and epilogue run beside the other's MFMAs, and nothing is double-buffered inside a wave.
-// Measured (bench.py, 8 tiles of 64^3 per launch, rocprofv3 kernel trace): 0.73 ms against 1.86 ms for the f32 VALU kernel it replaces
+// Measured (bench.py, 8 tiles of 64^3 per launch, rocprofv3 kernel trace): 0.68 ms against 1.86 ms for the f32 VALU kernel it replaces
 // (60 M MFMAs = 0.39 ms of issue at 2.4 GHz).  Ablations (-DMICA_STEM_NOLOOP: one K-step per kernel size; -DMICA_STEM_NOEPI: no
 // output) on the one-workgroup-per-CU version of 0.94 ms: 0.37 ms and 0.70 ms - the K loop was 0.57 ms (69 % MFMA-busy), the output
 // (1.07 GB of split records in 8-byte pieces) 0.24 ms, tile fill and launch 0.13 ms, all in sequence; pinning the weight prefetch,
 // batching the tile fill's loads, a conflict-free fragment mapping (y and y + 4 in one fragment) and all sixteen fragment reads up
 // front each changed nothing there; sharing the CU between two workgroups took it to 0.80 ms, removing that version's 26 spilled registers
-// (fragment addresses hoisted out of the size loop) to 0.73 ms.
+// (fragment addresses hoisted out of the size loop) to 0.73 ms, 16-byte instead of 8-byte output pieces to 0.68 ms.
 // Used for tile widths that are multiples of 64 (the production tile); other widths take the f32 VALU kernel (kernels_conv.hip:
 // stem_kernel), which writes the same formats.
 #include "common.h"
@@ -81,13 +81,15 @@ void stem_mfma_plan(const float* w, std::vector<float>& wf, std::vector<int>& ao
                 }
                 for (int t = 0; t < 2; ++t)
                     for (int lane = 0; lane < 64; ++lane) {
+                        // MFMA row m of channel tile t carries channel 8 (m >> 2) + 4 t + (m & 3): a lane's rows 4 g .. 4 g + 3 of the two
+                        // tiles are then the 8 consecutive channels 8 g .. 8 g + 7 (16-byte pieces of the output records)
                         const int m = lane & 15, g = lane >> 4, G = 4 * s + g;
                         for (int i = 0; i < 8; ++i) {
                             float v = 0.f;
                             if (G < (int)groups.size()) {
                                 const Grp& q = groups[G];
                                 const int kx = 8 * q.dl + i - c + R;
-                                if (kx >= 0 && kx < k) v = w[woff + ((size_t)(q.kz * k + q.ky) * k + kx) * 32 + t * 16 + m];
+                                if (kx >= 0 && kx < k) v = w[woff + ((size_t)(q.kz * k + q.ky) * k + kx) * 32 + 8 * (m >> 2) + 4 * t + (m & 3)];
                             }
                             wf.push_back(v);
                         }
@@ -226,12 +228,13 @@ __global__ __launch_bounds__(512, 4) void stem_mfma_kernel(const float* __restri
         // C/D map of the 16x16 MFMA: column = lane & 15 (voxel), rows (lane >> 4) * 4 + i (channels 4 g + i of the 16-channel tile t)
         // Everything is formed at the operand scale: xs = acc / wscale + bias * ascale = ascale * (acc * out_scale + bias) exactly (powers
         // of two), so the split encoder needs no multiply of its own; the channel sums and the raw output are scaled back by 1 / ascale.
+        // C/D map of the 16x16 MFMA: column = lane & 15 (voxel), rows (lane >> 4) * 4 + i of tile t = channels 8 g + 4 t + i (see the packing)
         float sums[2][4];
         float bv[2][4];
         const float xscale = out_scale * ascale, inv_ascale = 1.0f / ascale;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float4 q = *reinterpret_cast<const float4*>(bstem + sz * 32 + t * 16 + 4 * g);
+            const float4 q = *reinterpret_cast<const float4*>(bstem + sz * 32 + 8 * g + 4 * t);
             bv[t][0] = q.x * ascale; bv[t][1] = q.y * ascale; bv[t][2] = q.z * ascale; bv[t][3] = q.w * ascale;
 #pragma unroll
             for (int i = 0; i < 4; ++i) sums[t][i] = 0.f;
@@ -250,37 +253,40 @@ __global__ __launch_bounds__(512, 4) void stem_mfma_kernel(const float* __restri
             if (gy < d.H && gz < d.D) {
 #endif
                 const int64_t vox = (int64_t)(gz * d.H + gy) * d.W + gx;
+                float xs[8], cl[8];
+                bool viol = false;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float xs[4], cl[4];
-                    bool viol = false;
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        xs[i] = fmaf(acc[f][t][i], xscale, bv[t][i]);
-                        sums[t][i] += xs[i];
-                        cl[i] = __builtin_amdgcn_fmed3f(xs[i], -F16_LIMIT, F16_LIMIT);      // NaN -> -F16_LIMIT
-                        viol |= cl[i] != xs[i];
+                        const int j = 4 * t + i;
+                        xs[j] = fmaf(acc[f][t][i], xscale, bv[t][i]);
+                        sums[t][i] += xs[j];
+                        cl[j] = __builtin_amdgcn_fmed3f(xs[j], -F16_LIMIT, F16_LIMIT);      // NaN -> -F16_LIMIT
+                        viol |= cl[j] != xs[j];
                     }
-                    if (__builtin_amdgcn_ballot_w64(viol)) {          // wave-uniform slow path: which kind of violation
+                if (__builtin_amdgcn_ballot_w64(viol)) {          // wave-uniform slow path: which kind of violation
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (!(fabsf(xs[i]) <= F16_LIMIT)) bad |= (fabsf(xs[i]) <= 3.0e38f) ? RANGE_OVERFLOW : RANGE_NONFINITE;
-                    }
-                    if (out.p) {
-                        half4s hi, lo;
+                    for (int j = 0; j < 8; ++j)
+                        if (!(fabsf(xs[j]) <= F16_LIMIT)) bad |= (fabsf(xs[j]) <= 3.0e38f) ? RANGE_OVERFLOW : RANGE_NONFINITE;
+                }
+                if (out.p) {
+                    half8 hi, lo;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const _Float16 h = (_Float16)cl[i];
-                            hi[i] = h;
-                            lo[i] = (_Float16)(cl[i] - (float)h);
-                        }
-                        _Float16* dst = out.p + (((int64_t)b * out.chunks_total + out.chunk_off + sz * 2 + t) * V + vox) * 32;
-                        *reinterpret_cast<half4s*>(dst + 4 * g) = hi;
-                        *reinterpret_cast<half4s*>(dst + 16 + 4 * g) = lo;
+                    for (int j = 0; j < 8; ++j) {
+                        const _Float16 h = (_Float16)cl[j];
+                        hi[j] = h;
+                        lo[j] = (_Float16)(cl[j] - (float)h);
                     }
-                    if (out_raw)
-                        *reinterpret_cast<float4*>(out_raw + ((int64_t)b * V + vox) * 128 + sz * 32 + t * 16 + 4 * g) =
-                            make_float4(xs[0] * inv_ascale, xs[1] * inv_ascale, xs[2] * inv_ascale, xs[3] * inv_ascale);
+                    // channels 8 g .. 8 g + 7 of this kernel size: chunk sz * 2 + (g >> 1), halves (g & 1) * 8 .. of its hi and lo parts
+                    _Float16* dst = out.p + (((int64_t)b * out.chunks_total + out.chunk_off + sz * 2 + (g >> 1)) * V + vox) * 32 + (g & 1) * 8;
+                    *reinterpret_cast<half8*>(dst) = hi;
+                    *reinterpret_cast<half8*>(dst + 16) = lo;
+                }
+                if (out_raw) {
+                    float* dr = out_raw + ((int64_t)b * V + vox) * 128 + sz * 32 + 8 * g;
+                    *reinterpret_cast<float4*>(dr) = make_float4(xs[0] * inv_ascale, xs[1] * inv_ascale, xs[2] * inv_ascale, xs[3] * inv_ascale);
+                    *reinterpret_cast<float4*>(dr + 4) = make_float4(xs[4] * inv_ascale, xs[5] * inv_ascale, xs[6] * inv_ascale, xs[7] * inv_ascale);
                 }
             }
         }
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(512, 4) void stem_mfma_kernel(const float* __restri
                 SM_ROR_ADD(sv, 2);
                 SM_ROR_ADD(sv, 4);
                 SM_ROR_ADD(sv, 8);
-                if (n == 0) csum[wave][sz * 32 + t * 16 + 4 * g + i] = sv;
+                if (n == 0) csum[wave][sz * 32 + 8 * g + 4 * t + i] = sv;
             }
 #undef SM_ROR_ADD
     }
