@@ -318,6 +318,31 @@ def test_inline_asm_weight_prefetch_is_hazard_free(tmp_path):
     assert spills and max(spills) == 0, spills
 
 
+def test_stem_mfma_kernel_keeps_its_register_and_lds_budget(tmp_path):
+    """stem_mfma_kernel (kernels_stem.hip) shares a CU between two 512-thread workgroups: that needs <= 128 VGPRs per wave, no scratch
+    (26 spilled registers once cost 9 % of the kernel) and <= 80 KB of LDS; one copy of the K-step body (48 MFMAs, 16 fragment
+    reads).  Cross-compiles without a GPU."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "mica_amd", "csrc", "kernels_stem.hip")
+    asm = str(tmp_path / "kernels_stem.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", asm, src],
+                          stderr=subprocess.DEVNULL)
+    text = open(asm).read()
+    m = re.search(r"^_ZN4mica16stem_mfma_kernelE.*?s_endpgm", text, flags=re.S | re.M)
+    assert m
+    body = m.group(0)
+    assert body.count("v_mfma_f32_16x16x32_f16") == 48 and "scratch_" not in body
+    meta = re.search(r"\.group_segment_fixed_size:\s+(\d+)[^\n]*\n(?:[^\n]*\n)*?\s+\.name:\s+_ZN4mica16stem_mfma_kernelE.*?\.private_segment_fixed_size:\s+(\d+).*?"
+                     r"\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", text, flags=re.S)
+    assert meta, "kernel metadata not found"
+    lds, scratch, vgprs, spilled = (int(v) for v in meta.groups())
+    assert lds <= 80 * 1024 and scratch == 0 and vgprs <= 128 and spilled == 0, (lds, scratch, vgprs, spilled)
+
+
 def test_inline_asm_weight_prefetch_of_the_f43_kernel_is_hazard_free(tmp_path):
     """conv_wino43_kernel (kernels_conv43.hip): the same audit.  Per chunk and wave 14 steps of 16 MFMAs, ten weight-fragment sets in
     three register sets (40 asm loads), six slab DMAs, 36 A-fragment reads; the waits a step places leave exactly the fragments
