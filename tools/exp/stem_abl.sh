@@ -1,5 +1,6 @@
 #!/bin/bash
-# ablations of stem_mfma_kernel (one K-step per kernel size; no output): kernel-trace average of the stem kernel in bench.py
+# ablations of stem_mfma_kernel (dev builds: make -C mica_amd/csrc exp_stem; one K-step per kernel size; no output): kernel-trace average of
+# the stem kernel in bench.py
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/stemabl
