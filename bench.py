@@ -91,6 +91,47 @@ def cpu_baseline(weights, tiles_map, tiles_af, vol_host):
     return out
 
 
+def _newest(pattern):
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return c[-1] if c else None
+
+
+def load_traffic(src_hash, applicable):
+    """Per-kernel PMC HBM bytes per launch of the newest profiles/rNN_pmc_traffic.json, if it was collected on these sources."""
+    p = _newest("r[0-9][0-9]_pmc_traffic.json")
+    if not applicable or p is None:
+        return {}, "none (counter passes are taken at batch 8 on the AF path)" if p else "none"
+    d = json.load(open(p))
+    if d.get("library_source_hash") != src_hash:
+        return {}, f"{os.path.basename(p)} REFUSED: collected on library sources {d.get('library_source_hash')}, running {src_hash}"
+    return d.get("kernels", {}), os.path.basename(p)
+
+
+def load_sq_summary(src_hash, applicable):
+    """Per-kernel MFMA-busy share and held clock of the newest profiles/rNN_pmc_sq_summary.txt (tools/pmc_conv_summary.py), if it
+    was collected on these sources: {kernel: {calls, avg_us, clock_ghz, mfma_busy}}."""
+    p = _newest("r[0-9][0-9]_pmc_sq_summary.txt")
+    if not applicable or p is None:
+        return {}, "none"
+    rows, stamp = {}, None
+    for line in open(p):
+        if line.startswith("library_source_hash:"):
+            stamp = line.split(":", 1)[1].strip()
+            continue
+        f = line.split()
+        if len(f) < 11 or "kernel" not in f[0]:
+            continue
+        try:
+            nums = [float(v) for v in f[-10:]]
+        except ValueError:
+            continue
+        rows[" ".join(f[:-10])] = {"calls": nums[0], "avg_us": nums[1], "clock_ghz": nums[2], "mfma_busy": nums[3] / 100.0}
+    if stamp != src_hash:
+        return {}, f"{os.path.basename(p)} REFUSED: collected on library sources {stamp}, running {src_hash}"
+    return rows, os.path.basename(p)
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this one has not touched the GPU),
     relay their output; rank 0 prints the JSON line."""
@@ -337,56 +378,65 @@ def main():
         wms, wl, wflops = eng.profile(2)
         eng43 = eng.profile(5)
         eng.set_profiling(False)
-        traffic, tp = {}, None
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))   # re-collected whenever the conv kernels change
-        if cands and B == 8 and not args.no_af:                         # per launch at batch 8; independent of the map size
-            tp = cands[-1]
-            traffic = json.load(open(tp)).get("kernels", {})
-        tpn = os.path.basename(tp) if tp else "none"
-        ach_all = flops / (ms * 1e-3) / 1e12
-        wach = wflops / (wms * 1e-3) / 1e12 if wms > 0 else 0.0
+        # counter figures come from the committed rocprofv3 passes of tools/profile.sh (profiles/rNN_pmc_traffic.json,
+        # rNN_pmc_sq_summary.txt); each is stamped with the hash of the library sources it was collected on and is quoted only
+        # if that equals the running tree's - a kernel change without a re-profile yields null, not stale bytes
+        from mica_amd._cabi import source_hash
+        here = source_hash()
+        traffic, tnote = load_traffic(here, B == 8 and not args.no_af)
+        sq, sqnote = load_sq_summary(here, B == 8 and not args.no_af)
+        wach = wflops / (wms * 1e-3) / 1e12 if wms > 0 else 0.0          # algorithmic TF, F(2,3) launches
         fms, fl, fflops = eng43
-        fach = fflops / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
-        # executed f16 MFMA FLOPs of all 3^3 launches together over their time: the hardware fraction of the conv kernels
-        ex_all = (wflops * WINO_MFMA_PER_ALGORITHMIC + fflops * WINO43_MFMA_PER_ALGORITHMIC) / max((wms + fms) * 1e-3, 1e-12) / 1e12
-        w16 = {"kernel": "conv_wino16_kernel<128|64|32>: Winograd F(2,3)-x, the 3x3x3 convs outside encoder.2", "achieved": wach,
-               "frac": wach / PEAK_SPLIT_TF, "launches_per_batch": wl, "avg_launch_ms": wms / max(wl, 1),
-               "executed_mfma_frac": wach * WINO_MFMA_PER_ALGORITHMIC / PEAK_F16_MFMA_TF,
-               "traffic": traffic.get("conv_wino16_kernel", {}).get("hbm_bytes")}
+        fach = fflops / (fms * 1e-3) / 1e12 if fms > 0 else 0.0          # algorithmic TF, F(4,3) launches
+        ach_all = flops / (ms * 1e-3) / 1e12
+
+        def mfma_obj(name, key, alg_tf, fac, tms, n, alg_flops, sqkeys):
+            """Roofline of one 3^3 conv kernel against the dense f16 MFMA peak: achieved = f16 MFMA FLOPs the kernel ISSUES
+            (algorithmic direct-conv FLOPs x executed-per-algorithmic) / HIP-event time."""
+            o = {"kernel": name, "achieved": alg_tf * fac, "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": alg_tf * fac / PEAK_F16_MFMA_TF,
+                 "traffic": traffic.get(key, {}).get("hbm_bytes"), "launches_per_batch": n, "avg_launch_ms": tms / max(n, 1),
+                 "executed_gflop_per_launch_avg": alg_flops * fac / max(n, 1) / 1e9,
+                 "algorithmic_gflop_per_launch_avg": alg_flops / max(n, 1) / 1e9,
+                 "algorithmic_tflops": alg_tf, "executed_per_algorithmic": fac,
+                 "algorithmic_frac_of_split_f16_peak": alg_tf / PEAK_SPLIT_TF}
+            rows = [sq[k] for k in sqkeys if k in sq]
+            if rows:
+                t = sum(r["calls"] * r["avg_us"] for r in rows)
+                busy = sum(r["calls"] * r["avg_us"] * r["mfma_busy"] for r in rows) / t
+                clk = sum(r["calls"] * r["avg_us"] * r["clock_ghz"] for r in rows) / t
+                o.update(mfma_busy=busy, held_clock_ghz=clk, mfma_busy_x_clock_over_2p4=busy * clk / 2.4,
+                         profiled_avg_launch_ms=t / sum(r["calls"] for r in rows) / 1e3)
+            else:
+                o.update(mfma_busy=None, held_clock_ghz=None, mfma_busy_x_clock_over_2p4=None)
+            return o
+
+        w16 = mfma_obj("conv_wino16_kernel<128|64|32>: Winograd F(2,3)-x, the 3x3x3 convs outside encoder.2", "conv_wino16_kernel", wach,
+                       WINO_MFMA_PER_ALGORITHMIC, wms, wl, wflops, ["conv_wino16_kernel<128>", "conv_wino16_kernel<64>", "conv_wino16_kernel<32>"])
         if fl > 0:
-            dom_name = ("conv_wino43_kernel: the four 3x3x3 convs of encoder.2 (68 % of the network's FLOPs) via Winograd F(4,3)-x, split-f16 x3 MFMA "
-                        "(v_mfma_f32_16x16x32_f16)")
-            dach_, dms_, dl_, dfl_, dfac, dkey = fach, fms, fl, fflops, WINO43_MFMA_PER_ALGORITHMIC, "conv_wino43_kernel"
+            roof = mfma_obj("conv_wino43_kernel: the four 3x3x3 convs of encoder.2 (68 % of the network's FLOPs) via Winograd F(4,3)-x, split-f16 x3 "
+                            "MFMA (v_mfma_f32_16x16x32_f16)", "conv_wino43_kernel", fach, WINO43_MFMA_PER_ALGORITHMIC, fms, fl, fflops, ["conv_wino43_kernel"])
+            roof["conv_wino16"] = w16
         else:
-            dom_name = "conv_wino16_kernel: every dense 3x3x3 conv via Winograd F(2,3)-x, split-f16 x3 MFMA (v_mfma_f32_16x16x32_f16)"
-            dach_, dms_, dl_, dfl_, dfac, dkey = wach, wms, wl, wflops, WINO_MFMA_PER_ALGORITHMIC, "conv_wino16_kernel"
-        roof = {"bound": "mfma", "kernel": dom_name,
-                "achieved": dach_, "peak": PEAK_SPLIT_TF, "unit": "TFLOP/s", "frac": dach_ / PEAK_SPLIT_TF,
-                "traffic": traffic.get(dkey, {}).get("hbm_bytes"),
-                "launches_per_batch": dl_, "avg_launch_ms": dms_ / max(dl_, 1),
-                "algorithmic_gflop_per_launch_avg": dfl_ / max(dl_, 1) / 1e9,
-                "executed_mfma": {"achieved": dach_ * dfac, "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s (f16 MFMA issued)",
-                                  "frac": dach_ * dfac / PEAK_F16_MFMA_TF,
-                                  "note": "algorithmic FLOPs / 2 (Winograd F(4,3): 13.5 instead of 27 MFMA-taps per output; / 1.5 for the F(2,3) kernel) x 3 "
-                                          "(split products) x 14/13.5 (tap pairing) = f16 MFMA FLOPs the kernel issues, over the 2.5 PF dense f16 peak: "
-                                          "the hardware fraction"},
-                "conv_wino16": w16,
-                "all_3x3x3_convs": {"launches_per_batch": wl + fl, "ms_per_batch": wms + fms,
-                                    "achieved": (wflops + fflops) / max((wms + fms) * 1e-3, 1e-12) / 1e12,
-                                    "executed_mfma_frac": ex_all / PEAK_F16_MFMA_TF},
-                "all_dense_convs": {"achieved": ach_all, "frac": ach_all / PEAK_SPLIT_TF, "launches_per_batch": launches,
-                                    "note": "3x3x3 and 1x1x1 launches together (the 1x1 kernel is HBM-bound and also does the operand passes)"},
-                "note": "achieved = algorithmic direct-conv FLOPs (2*27*Cin*Cout*V, unpadded) of the dominant kernel's launches of one batch / their "
-                        "HIP-event time on the launch stream (avg_launch_ms: compare the kernel-trace summary under profiles/ for this round); peak = f16 "
-                        "dense MFMA 2500 TF / 3 MFMAs per f32-grade product (833 TF); Winograd executes fewer MFMAs than the algorithmic count, so `frac` "
-                        "is an algorithmic rate (it may exceed 1) and `executed_mfma` the hardware fraction; traffic = PMC HBM bytes per launch at batch 8 "
-                        "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections, profiles/" + tpn + "); null for other batch sizes"}
+            roof = w16
+        ex_all = (wflops * WINO_MFMA_PER_ALGORITHMIC + fflops * WINO43_MFMA_PER_ALGORITHMIC) / max((wms + fms) * 1e-3, 1e-12) / 1e12
+        roof = dict({"bound": "mfma"}, **roof)
+        roof["all_3x3x3_convs"] = {"launches_per_batch": wl + fl, "ms_per_batch": wms + fms, "achieved": ex_all, "peak": PEAK_F16_MFMA_TF,
+                                   "frac": ex_all / PEAK_F16_MFMA_TF,
+                                   "algorithmic_tflops": (wflops + fflops) / max((wms + fms) * 1e-3, 1e-12) / 1e12}
+        roof["all_dense_convs"] = {"algorithmic_tflops": ach_all, "launches_per_batch": launches, "ms_per_batch": ms,
+                                   "note": "3x3x3 and 1x1x1 launches together (the 1x1 kernel is HBM-bound and also does the operand passes)"}
+        roof["profile_source"] = {"library_source_hash": here, "traffic": tnote, "counters": sqnote}
+        roof["note"] = ("achieved = f16 MFMA FLOPs the dominant kernel issues per launch (algorithmic direct-conv FLOPs 2*27*Cin*Cout*V, unpadded, x "
+                        "executed_per_algorithmic: / 2 for Winograd F(4,3) [/ 1.5 for F(2,3)] x 3 split products x 14/13.5 tap pairing) / average launch "
+                        "time from HIP events on the launch stream; peak = 2500 TF dense f16 MFMA; frac is a hardware fraction (<= 1) and should equal "
+                        "mfma_busy x held_clock / 2.4 GHz from the SQ counters of the same tree; the algorithmic rate (which credits Winograd's saving "
+                        "and the 3-product split: 833 TF ceiling) is in algorithmic_tflops; traffic = PMC HBM bytes per launch at batch 8 (rocprofv3 "
+                        "--pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections), null when the committed profile was taken on other library sources")
         dach = dbytes / (dms * 1e-3) / 1e9
         hbm = {"bound": "hbm", "kernel": "depthwise_kernel (Conv3d groups=C, 3x3x3, IN+ReLU+SE gate fused on load, IN stats fused)",
                "achieved": dach, "peak": 8000.0, "unit": "GB/s", "frac": dach / 8000.0,
                "traffic": traffic.get("depthwise_kernel", {}).get("hbm_bytes"), "launches_per_batch": dl,
-               "avg_launch_ms": dms / max(dl, 1),
+               "avg_launch_ms": dms / max(dl, 1), "algorithmic_bytes_per_launch": dbytes / max(dl, 1),
                "note": "BASELINE metric's 'HBM GB/s on conv3d': algorithmic 8 B per voxel and channel / HIP-event time"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
@@ -409,6 +459,10 @@ def main():
                        "backend": args.backend if grouped else None,
                        "tiles_per_step": B * world, "af_path": not args.no_af, "flops_per_tile": FLOPS_PER_TILE_AF,
                        "seconds_per_map": T / value},
+            "sustained": None if whole is None else {
+                "value": whole["value"], "unit": "sub-grids/s", "seconds": whole["predict_seconds"], "tiles": whole["tiles"],
+                "note": "ONE complete map, every window of the reference tiling (48, 8), wall clock: what the power-bound kernel mix holds "
+                        "over a whole map; `value` above is the contract's K timed steps (a ~2-s window, typically 2-3 % higher)"},
             "alt_tiling": alt, "whole_map": whole, "roofline": roof, "hbm_conv3d": hbm, "cpu_baseline": cpu})
     if grouped:
         dist.barrier()                          # rank 0 ran the extra profiled batch: leave together

@@ -20,6 +20,10 @@
  *       mica_get_last_forward_scale), mica_finalize_weights, mica_normalise_map*, mica_zoom_cubic*, mica_rasterise_atoms, the point-list
  *       functions and every mica_op_*.  A host pipeline that wants to overlap uploads with a forward does so from a second stream /
  *       thread (mica_amd/predict.py, mica_amd/pipeline.py::predict_maps_streamed), not by relying on the forward returning early.
+ *   - the HIP runtime's thread-local "last error" belongs to the host program: the library never clears an error it did not cause.
+ *     A call made while such an error is pending on the calling thread returns MICA_ERR_STATE without launching anything and leaves
+ *     the error where the host will find it (hipGetLastError()); the library's own failures are reported through the return code
+ *     and cleared.  No entry point aborts the process: a shape a kernel cannot take is MICA_ERR_ARG.
  *   - volumes are C-contiguous [N0][N1][N2] in the (x,y,z) index order the reference uses after
  *     GridCreator.transpose (create_grids.py:67-87); tiles are [W][W][W], W = grid + 2*pad.
  */
@@ -102,6 +106,11 @@ int mica_forward_tiles(mica_ctx* ctx, const float* d_map, const float* d_af, int
  * backbone probability, 1 carbon-alpha probability, 2 amino-acid prediction (0..19 as float), 3..22 amino-acid probabilities -
  * the layout mica_stitch_tiles scatters into the four volumes and that the multi-GPU exchange ships (no repacking copies).  */
 int mica_forward_records(mica_ctx* ctx, const float* d_map, const float* d_af, int batch, int af_mode, float* d_rec, void* stream);
+/* h_sums f32[batch] = |d_af[b]|.sum() per tile (d_af f32[batch][24][S^3], any batch >= 1): the device reduction the forward calls
+ * use for the test `af_features.abs().sum() < 1e-6` of models/model.py:60, for a host that cuts one batch into several calls and
+ * evaluates the batch-wide test itself (then MICA_AF_ALWAYS / MICA_AF_NONE) - summing these in double, as the library does for
+ * MICA_AF_BATCH, gives the same decision on either side of max_batch.  Synchronous; no temporary of the batch's size.            */
+int mica_af_abs_sums(mica_ctx* ctx, const float* d_af, int64_t batch, float* h_sums, void* stream);
 /* Post-processing alone (predict.py:342-349) on NCDHW logits. */
 int mica_postprocess(mica_ctx* ctx, const float* d_bb, const float* d_ca, const float* d_aa, int batch,
                      float* d_bb_prob, float* d_ca_prob, float* d_aa_prob, float* d_aa_pred, void* stream);
@@ -225,6 +234,8 @@ int mica_neighbour_matrix_np(mica_ctx* ctx, const double* d_cands, int64_t n, co
                              int numpy_rules, double* d_dis, double* d_mat, void* stream);
 
 /* ---- single-op entry points (parity tests drive each kernel through the ABI) -------------- */
+/* Box limits of all of them: 1 <= batch <= 64 and every edge d, h, w in [1, 128] (the edges mica_create_dims admits: the conv
+ * kernels address their operand slabs with 32-bit offsets sized for that), channel counts <= 1024; beyond -> MICA_ERR_ARG.      */
 /* Conv3d k in {1,3}, stride 1, 'same' zero padding, on the split-f16 MFMA path.
  * d_x f32[B][Cin][D][H][W] NCDHW, h_w f32[Cout][Cin][k][k][k], h_b f32[Cout] -> d_y f32[B][Cout][D][H][W]. */
 int mica_op_conv3d(mica_ctx* ctx, const float* d_x, int batch, int cin, int d, int h, int w,

@@ -8,6 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmica_hip.so")
 
+ABI_VERSION = 2          # mica_abi_version() of the library these signatures describe (bumped whenever an export or a struct changes)
 MICA_OK = 0
 MICA_ERR_ARG, MICA_ERR_HIP, MICA_ERR_STATE, MICA_ERR_RANGE = -1, -2, -3, -4
 AF_NONE, AF_PER_TILE, AF_BATCH, AF_ALWAYS = 0, 1, 2, 3
@@ -31,6 +32,7 @@ SIGNATURES = {
     "mica_forward_logits": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "mica_forward_tiles": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "mica_forward_records": (_I, [_P, _P, _P, _I, _I, _P, _P]),
+    "mica_af_abs_sums": (_I, [_P, _P, _L, _FP, _P]),
     "mica_postprocess": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "mica_tile_count": (_L, [_L, _L, _L, _I]),
     "mica_tile_table": (_L, [_L, _L, _L, _I, _LP, _L]),
@@ -72,6 +74,20 @@ SIGNATURES = {
 _lib = None
 
 
+def source_hash() -> str:
+    """SHA-256 over the library's sources (mica_amd/csrc/*.hip, common.h, Makefile and include/mica_hip.h, in name order).
+    tools/profile.sh stamps every rocprofv3 summary it writes under profiles/ with it and bench.py only quotes counter figures whose
+    stamp equals the running tree's (.git does not travel to the GPU box, so a content hash stands in for the git tree id)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    names = sorted(f for f in os.listdir(src) if f.endswith((".hip", ".h")) or f == "Makefile")
+    for f in [os.path.join(src, n) for n in names] + [os.path.join(os.path.dirname(_HERE), "include", "mica_hip.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 class MicaHipError(RuntimeError):
     pass
 
@@ -92,6 +108,11 @@ def load_library(path: str | None = None):
             f"{p} not found: build it with `make -C mica_amd/csrc` (or __graft_entry__.build()). "
             "mica_amd has no CPU fallback.")
     lib = C.CDLL(p)
+    lib.mica_abi_version.restype = C.c_int
+    v = lib.mica_abi_version()
+    if v != ABI_VERSION:
+        raise MicaHipError(f"{p} has ABI version {v}, this package binds version {ABI_VERSION}: a stale build - rebuild it with "
+                           "`make -C mica_amd/csrc` (the library is git-ignored, it does not follow a checkout)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res

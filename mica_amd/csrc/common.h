@@ -10,6 +10,13 @@
 
 namespace mica {
 
+// A launch helper that is handed a shape its kernel cannot take does NOT launch and records why (first refusal wins); the C-ABI entry
+// points turn a recorded refusal into MICA_ERR_ARG + mica_last_error (forward.hip: CHECK_LAUNCHES).  Nothing in the library aborts
+// the host process.
+inline thread_local const char* g_launch_refusal = nullptr;
+inline void refuse_launch(const char* why) { if (!g_launch_refusal) g_launch_refusal = why; }
+inline const char* take_launch_refusal() { const char* w = g_launch_refusal; g_launch_refusal = nullptr; return w; }
+
 // Once-per-device initialisation of a launcher (dynamic-LDS limit of its kernels, CU count) that holds when several host threads drive
 // different contexts ("different ctxs are independent", include/mica_hip.h): a device's flag is published only AFTER `init(dev)` has
 // run, so no thread can launch with a limit that is not set yet or read a CU count that is not written yet; two threads running

@@ -129,13 +129,35 @@ namespace {
             return MICA_ERR_HIP;                                                                     \
         }                                                                                            \
     } while (0)
-// Entry of every call that launches work: the context's device becomes current, and a stale error of an EARLIER call (ours, already
-// reported through its return code, or the host program's) is dropped so that the hipGetLastError() checks below speak about this
-// call's launches only (a failed hipMalloc of a refused context used to fail the next context's mica_finalize_weights).
+// Entry of every call that launches work: the context's device becomes current.  The runtime's thread-local last error is NOT
+// cleared here: an error of the host program that is still pending on this thread (say a failed launch of its own that it has not
+// looked at yet) stays where the host will find it, and the call is refused rather than launched behind it - the launch checks at
+// the end of a call (CHECK_LAUNCHES) could not tell it from an error of this call's launches.  (The library's own failed hipMallocs
+// clear what they report: dalloc, Tmp::get.)  hipErrorNotReady is a status of hipEventQuery / hipStreamQuery, not a failure.
 #define MICA_ENTER(ctx)                                                                              \
     do {                                                                                             \
         HIPC(ctx, hipSetDevice((ctx)->device));                                                      \
-        (void)hipGetLastError();                                                                     \
+        hipError_t pre_ = hipPeekAtLastError();                                                      \
+        if (pre_ != hipSuccess && pre_ != hipErrorNotReady) {                                        \
+            (ctx)->err = std::string("a HIP error of the calling program is pending on this thread (") + hipGetErrorString(pre_) + \
+                         "): left in place, nothing launched";                                       \
+            return MICA_ERR_STATE;                                                                   \
+        }                                                                                            \
+        (void)take_launch_refusal();                                                                 \
+    } while (0)
+// After the launches of a call: a launch helper that refused its shape (common.h: refuse_launch) -> MICA_ERR_ARG; a failed launch ->
+// MICA_ERR_HIP.
+#define CHECK_LAUNCHES(ctx)                                                                          \
+    do {                                                                                             \
+        if (const char* why_ = take_launch_refusal()) {                                              \
+            (ctx)->err = why_;                                                                       \
+            return MICA_ERR_ARG;                                                                     \
+        }                                                                                            \
+        hipError_t e_ = hipGetLastError();                                                           \
+        if (e_ != hipSuccess && e_ != hipErrorNotReady) {                                            \
+            (ctx)->err = std::string("kernel launch: ") + hipGetErrorString(e_);                     \
+            return MICA_ERR_HIP;                                                                     \
+        }                                                                                            \
     } while (0)
 
 template <typename T> int dalloc(mica_ctx* c, T** p, int64_t n) {
@@ -481,7 +503,7 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
         if (r) return r;
         b0 = b1;
     }
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     if (c->profiling) {
         HIPC(c, hipStreamSynchronize(st));
         double ms[PROF_KINDS] = {};
@@ -512,6 +534,10 @@ struct Tmp {
     }
 };
 bool pow2_8_512(int c) { return c >= 8 && c <= 512 && (c & (c - 1)) == 0; }
+// Box limits of the single-op entry points: the same edges mica_create_dims admits (the conv kernels index their slabs with 32-bit
+// offsets, sized for edges <= 128), at most 64 tiles per call.
+bool op_box_ok(int batch, int d, int h, int w) { return batch >= 1 && batch <= 64 && d >= 1 && d <= 128 && h >= 1 && h <= 128 && w >= 1 && w <= 128; }
+#define OP_BOX_MSG " [box limits: 1 <= batch <= 64, edges in [1, 128]]"
 }  // namespace
 
 
@@ -570,7 +596,7 @@ static int forward_checked(mica_ctx* c, const float* d_map, const float* d_af, i
 // =================================================================================================
 extern "C" {
 
-int mica_abi_version(void) { return 1; }
+int mica_abi_version(void) { return 2; }
 
 const char* mica_last_error(const mica_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -785,7 +811,7 @@ int mica_finalize_weights(mica_ctx* c) {
         if ((r = upload(c, &H.bf, bf->data))) return r;
     }
     HIPC(c, hipDeviceSynchronize());
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     c->host.clear();
     c->finalized = true;
     return MICA_OK;
@@ -804,7 +830,7 @@ int mica_postprocess(mica_ctx* c, const float* d_bb, const float* d_ca, const fl
     if (!d_bb || !d_ca || !d_aa || !d_bb_prob || !d_ca_prob || !d_aa_prob || !d_aa_pred || batch < 1) { c->err = "mica_postprocess: bad argument"; return MICA_ERR_ARG; }
     MICA_ENTER(c);
     launch_postprocess(d_bb, d_ca, d_aa, batch, c->V, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, c->V, (int64_t)20 * c->V, (hipStream_t)stream);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     return MICA_OK;
 }
 
@@ -817,6 +843,24 @@ int mica_forward_tiles(mica_ctx* c, const float* d_map, const float* d_af, int b
     return mica_postprocess(c, c->logits[0], c->logits[1], c->logits[2], batch, d_bb_prob, d_ca_prob, d_aa_prob, d_aa_pred, stream);
 }
 
+int mica_af_abs_sums(mica_ctx* c, const float* d_af, int64_t batch, float* h_sums, void* stream) {
+    if (!c) return MICA_ERR_ARG;
+    if (!d_af || !h_sums || batch < 1) { c->err = "mica_af_abs_sums: bad argument"; return MICA_ERR_ARG; }
+    MICA_ENTER(c);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t per = (int64_t)24 * c->V;
+    for (int64_t b0 = 0; b0 < batch; b0 += c->maxB) {           // the reduction of forward_impl, max_batch tiles at a time
+        const int n = (int)std::min<int64_t>(c->maxB, batch - b0);
+        HIPC(c, hipMemsetAsync(c->v_abs, 0, sizeof(float) * n, st));
+        launch_abs_sum(d_af + b0 * per, n, per, c->v_abs, st);
+        HIPC(c, hipMemcpyAsync(c->h_abs, c->v_abs, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+        CHECK_LAUNCHES(c);
+        HIPC(c, hipStreamSynchronize(st));
+        for (int b = 0; b < n; ++b) h_sums[b0 + b] = c->h_abs[b];
+    }
+    return MICA_OK;
+}
+
 int mica_forward_records(mica_ctx* c, const float* d_map, const float* d_af, int batch, int af_mode, float* d_rec, void* stream) {
     if (!c) return MICA_ERR_ARG;
     if (!d_rec) { c->err = "mica_forward_records: null pointer argument"; return MICA_ERR_ARG; }
@@ -825,7 +869,7 @@ int mica_forward_records(mica_ctx* c, const float* d_map, const float* d_af, int
     if (r) return r;
     const int64_t V = c->V;
     launch_postprocess(c->logits[0], c->logits[1], c->logits[2], batch, c->V, d_rec, d_rec + V, d_rec + 3 * V, d_rec + 2 * V, 23 * V, 23 * V, st);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     return MICA_OK;
 }
 
@@ -868,7 +912,7 @@ int mica_gather_tiles(mica_ctx* c, const float* d_vol, int channels, int64_t n0,
     if (r || count == 0) return r;
     MICA_ENTER(c);
     launch_gather_tiles(d_vol, channels, n0, n1, n2, grid, pad, first, count, d_tiles, (hipStream_t)stream);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     return MICA_OK;
 }
 
@@ -879,7 +923,7 @@ int mica_gather_tiles_u8(mica_ctx* c, const uint8_t* d_vol, int channels, int64_
     if (r || count == 0) return r;
     MICA_ENTER(c);
     launch_gather_tiles_u8(d_vol, channels, n0, n1, n2, grid, pad, first, count, d_tiles, (hipStream_t)stream);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     return MICA_OK;
 }
 
@@ -890,7 +934,7 @@ int mica_stitch_tiles(mica_ctx* c, const float* d_tiles, int channels, int64_t n
     if (r || count == 0) return r;
     MICA_ENTER(c);
     launch_stitch_tiles(d_tiles, channels, n0, n1, n2, grid, pad, first, count, d_vol, (hipStream_t)stream);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     return MICA_OK;
 }
 
@@ -1049,9 +1093,9 @@ int mica_op_conv3d(mica_ctx* c, const float* d_x, int batch, int cin, int d, int
 int mica_op_conv3d_variant(mica_ctx* c, const float* d_x, int batch, int cin, int d, int h, int w, const float* h_w, const float* h_b,
                            int cout, int k, int variant, float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
-    if (!d_x || !h_w || !h_b || !d_y || batch < 1 || cin < 1 || cout < 32 || cout % 32 || (k != 1 && k != 3) || d < 1 || h < 1 || w < 1 ||
+    if (!d_x || !h_w || !h_b || !d_y || batch < 1 || cin < 1 || cin > 1024 || cout < 32 || cout > 1024 || cout % 32 || (k != 1 && k != 3) || !op_box_ok(batch, d, h, w) ||
         (k == 1 && cout != 64 && cout != 128 && cout != 256) || variant < 0 || variant > 1 || (variant == 1 && (k != 3 || cout % 128))) {
-        c->err = "mica_op_conv3d: bad argument (k = 3: cout a multiple of 32, of 128 for the F(4,3) variant; k = 1: cout in {64, 128, 256})";
+        c->err = "mica_op_conv3d: bad argument (k = 3: cout a multiple of 32, of 128 for the F(4,3) variant; k = 1: cout in {64, 128, 256}; cin <= 1024)" OP_BOX_MSG;
         return MICA_ERR_ARG;
     }
     const bool f43 = variant == 1;
@@ -1096,7 +1140,7 @@ int mica_op_conv3d_variant(mica_ctx* c, const float* d_x, int batch, int cin, in
                        SplitEnc{derr, ASCALE_DEFAULT}, st);
     }
     launch_nhwc_to_nchw(raw, batch, cout, V, d_y, st);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     HIPC(c, hipStreamSynchronize(st));
     return MICA_OK;
 }
@@ -1111,8 +1155,8 @@ int mica_op_norm_conv1_conv3_variant(mica_ctx* c, const float* d_x, int batch, i
     if (!c) return MICA_ERR_ARG;
     const bool f43 = variant == 1;
     if (!d_x || !h_w1 || !h_b1 || !h_w3 || !h_b3 || !d_y || batch < 1 || cin < 16 || !pow2_8_512(cin) || (cmid != 64 && cmid != 128 && cmid != 256) ||
-        cout < 32 || cout % 32 || d < 1 || h < 1 || w < 1 || variant < 0 || variant > 1 || (f43 && cout % 128)) {
-        c->err = "mica_op_norm_conv1_conv3: bad argument (cin a power of two in [16,512], cmid in {64,128,256}, cout a multiple of 32)";
+        cout < 32 || cout > 1024 || cout % 32 || !op_box_ok(batch, d, h, w) || variant < 0 || variant > 1 || (f43 && cout % 128)) {
+        c->err = "mica_op_norm_conv1_conv3: bad argument (cin a power of two in [16,512], cmid in {64,128,256}, cout a multiple of 32, <= 1024)" OP_BOX_MSG;
         return MICA_ERR_ARG;
     }
     MICA_ENTER(c);
@@ -1167,14 +1211,14 @@ int mica_op_norm_conv1_conv3_variant(mica_ctx* c, const float* d_x, int batch, i
     if (f43) launch_conv_wino43(cs, pk3, 0, db3, 1.0f / (s3 * asc3), raw, batch, dm, cout, nullptr, st);
     else launch_conv_wino(cs, pk3, 0, db3, 1.0f / (s3 * ASCALE_DEFAULT), raw, batch, dm, cout, nullptr, st);
     launch_nhwc_to_nchw(raw, batch, cout, V, d_y, st);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     HIPC(c, hipStreamSynchronize(st));
     return MICA_OK;
 }
 
 int mica_op_instnorm_relu(mica_ctx* c, const float* d_x, int batch, int ch, int d, int h, int w, float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
-    if (!d_x || !d_y || batch < 1 || !pow2_8_512(ch) || d < 1 || h < 1 || w < 1) { c->err = "mica_op_instnorm_relu: bad argument (C must be a power of two in [8,512])"; return MICA_ERR_ARG; }
+    if (!d_x || !d_y || batch < 1 || !pow2_8_512(ch) || !op_box_ok(batch, d, h, w)) { c->err = "mica_op_instnorm_relu: bad argument (C must be a power of two in [8,512])" OP_BOX_MSG; return MICA_ERR_ARG; }
     MICA_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
     const int V = d * h * w;
@@ -1190,7 +1234,7 @@ int mica_op_instnorm_relu(mica_ctx* c, const float* d_x, int batch, int ch, int 
     launch_stats(a, batch, V, ch, 1e-5f, mean, rstd, ws, st);
     launch_prep(a, batch, V, ch, mean, rstd, 1, nullptr, SplitView{nullptr, 0, 0, 0}, b, nullptr, ws, SplitEnc{derr, ASCALE_DEFAULT}, st);
     launch_nhwc_to_nchw(b, batch, ch, V, d_y, st);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     HIPC(c, hipStreamSynchronize(st));
     return MICA_OK;
 }
@@ -1198,8 +1242,8 @@ int mica_op_instnorm_relu(mica_ctx* c, const float* d_x, int batch, int ch, int 
 int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, int h, int w, const float* h_w, const float* h_b,
                        float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
-    if (!d_x || !d_y || !h_w || !h_b || batch < 1 || ch < 16 || ch % 16 || d < 1 || h < 1 || w < 1) {
-        c->err = "mica_op_depthwise3: bad argument (C must be a multiple of 16)";
+    if (!d_x || !d_y || !h_w || !h_b || batch < 1 || ch < 16 || ch > 1024 || ch % 16 || !op_box_ok(batch, d, h, w)) {
+        c->err = "mica_op_depthwise3: bad argument (C must be a multiple of 16, <= 1024)" OP_BOX_MSG;
         return MICA_ERR_ARG;
     }
     MICA_ENTER(c);
@@ -1219,7 +1263,7 @@ int mica_op_depthwise3(mica_ctx* c, const float* d_x, int batch, int ch, int d, 
     launch_nchw_to_nhwc(d_x, batch, ch, V, a, st);
     launch_depthwise(a, batch, Dims{d, h, w}, ch, nullptr, nullptr, nullptr, dw, db, b, nullptr, nullptr, st);
     launch_nhwc_to_nchw(b, batch, ch, V, d_y, st);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     HIPC(c, hipStreamSynchronize(st));
     return MICA_OK;
 }
@@ -1228,8 +1272,8 @@ int mica_op_se_depthwise(mica_ctx* c, const float* d_x, int batch, int ch, int d
                          const float* h_fc0_w, const float* h_fc0_b, const float* h_fc3_w, const float* h_fc3_b, float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
     if (!d_x || !d_y || !h_dw_w || !h_dw_b || !h_fc0_w || !h_fc0_b || !h_fc3_w || !h_fc3_b || batch < 1 || ch < 32 || ch > 256 || !pow2_8_512(ch) ||
-        d < 1 || h < 1 || w < 1) {
-        c->err = "mica_op_se_depthwise: bad argument (C a power of two in [32, 256])";
+        !op_box_ok(batch, d, h, w)) {
+        c->err = "mica_op_se_depthwise: bad argument (C a power of two in [32, 256])" OP_BOX_MSG;
         return MICA_ERR_ARG;
     }
     MICA_ENTER(c);
@@ -1269,7 +1313,7 @@ int mica_op_se_depthwise(mica_ctx* c, const float* d_x, int batch, int ch, int d
     launch_stats_finalize(ws, batch, P, ch, 1e-5f, m1, r1, st, gse);                        // the SE gate folded into the norm constants
     launch_prep(u, batch, V, ch, m1, r1, 1, nullptr, SplitView{nullptr, 0, 0, 0}, y, nullptr, ws, SplitEnc{derr, ASCALE_DEFAULT}, st);
     launch_nhwc_to_nchw(y, batch, ch, V, d_y, st);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     HIPC(c, hipStreamSynchronize(st));
     return MICA_OK;
 }
@@ -1277,7 +1321,7 @@ int mica_op_se_depthwise(mica_ctx* c, const float* d_x, int batch, int ch, int d
 int mica_op_stem(mica_ctx* c, const float* d_map, int batch, int d, int h, int w, float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
     if (!c->finalized) { c->err = "weights not finalized"; return MICA_ERR_STATE; }
-    if (!d_map || !d_y || batch < 1 || d < 1 || h < 1 || w < 1) { c->err = "mica_op_stem: bad argument"; return MICA_ERR_ARG; }
+    if (!d_map || !d_y || batch < 1 || !op_box_ok(batch, d, h, w)) { c->err = "mica_op_stem: bad argument" OP_BOX_MSG; return MICA_ERR_ARG; }
     MICA_ENTER(c);
     hipStream_t st = (hipStream_t)stream;
     const int V = d * h * w;
@@ -1286,7 +1330,7 @@ int mica_op_stem(mica_ctx* c, const float* d_map, int batch, int d, int h, int w
     if (!raw) { c->err = "hipMalloc failed"; return MICA_ERR_HIP; }
     run_stem(c, d_map, batch, Dims{d, h, w}, SplitView{nullptr, 0, 0, 0}, raw, nullptr, SplitEnc{nullptr, ASCALE_DEFAULT}, st);
     launch_nhwc_to_nchw(raw, batch, 128, V, d_y, st);
-    HIPC(c, hipGetLastError());
+    CHECK_LAUNCHES(c);
     HIPC(c, hipStreamSynchronize(st));
     return MICA_OK;
 }

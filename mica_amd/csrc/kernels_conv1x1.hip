@@ -352,7 +352,7 @@ void launch_conv1x1(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstri
         total += src.s[i].chunks;
         // the norm table in LDS holds 512 channels per raw source (the widest tensor of the network); shapes are fixed by the
         // forward graph and checked by the single-op entry points
-        if (src.s[i].kind == 1 && src.s[i].chunks_total * 16 > 512) { fprintf(stderr, "conv1x1: raw source wider than 512 channels\n"); abort(); }
+        if (src.s[i].kind == 1 && src.s[i].chunks_total * 16 > 512) { refuse_launch("conv1x1: raw source wider than 512 channels"); return; }
     }
     const int w = wino.p != nullptr ? (wino_kind == 2 ? 2 : 1) : 0;
 #define C1_GO(NCT)                                                                                                                      \

@@ -552,8 +552,8 @@ extern "C" int mica_debug_conv43(unsigned* h_out, int n) {
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null): f32 [B][P][cout][3].
 int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out,
                        int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
-    if (!conv_wino43_eligible(cout)) { fprintf(stderr, "conv_wino43: cout must be a multiple of 128\n"); abort(); }
-    if ((int64_t)d.D * d.H * ((d.W + 3) / 4) * 24 * 16 >= (1ll << 31)) { fprintf(stderr, "conv_wino43: tile too large for 32-bit slab offsets\n"); abort(); }
+    if (!conv_wino43_eligible(cout)) { refuse_launch("conv_wino43: cout must be a multiple of 128"); return 0; }
+    if ((int64_t)d.D * d.H * ((d.W + 3) / 4) * 24 * 16 >= (1ll << 31)) { refuse_launch("conv_wino43: tile too large for 32-bit slab offsets"); return 0; }
     int total = 0;
     for (int i = 0; i < s.n; ++i) total += s.chunks[i];
     const int ntx = (d.W + 4 * Geo43::QX - 1) / (4 * Geo43::QX), nty = (d.H + Geo43::TY - 1) / Geo43::TY, ntz = (d.D + Geo43::TZ - 1) / Geo43::TZ,

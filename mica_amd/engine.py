@@ -40,6 +40,8 @@ class Engine:
         self.tile_shape = tuple(int(v) for v in tile_size) if isinstance(tile_size, (tuple, list)) else (int(tile_size),) * 3
         if len(self.tile_shape) != 3:
             raise MicaHipError(f"tile_size must be an int or (D, H, W), got {tile_size!r}")
+        if conv_variant is not None and int(conv_variant) not in (0, 1, 2):       # before the context (tens of GB of workspace) exists
+            raise MicaHipError(f"conv_variant must be None, 0, 1 or 2, got {conv_variant!r}")
         self.tile_size = self.tile_shape[0] if len(set(self.tile_shape)) == 1 else None      # None: non-cubic, forward_logits only
         h = C.c_void_p()
         with torch.cuda.device(self.device):          # the ambient current device of the caller is left alone
@@ -47,9 +49,13 @@ class Engine:
         if r != 0:
             raise MicaHipError(f"mica_create failed ({r}): {self.lib.mica_last_error(None).decode()}")
         self._h = h
-        if conv_variant is not None:
-            self._check(self.lib.mica_set_conv_variant(self._h, int(conv_variant)), "mica_set_conv_variant")
-        self.conv_variant = int(self.lib.mica_get_conv_variant(self._h))
+        try:
+            if conv_variant is not None:
+                self._check(self.lib.mica_set_conv_variant(self._h, int(conv_variant)), "mica_set_conv_variant")
+            self.conv_variant = int(self.lib.mica_get_conv_variant(self._h))
+        except Exception:
+            self.close()                   # a context that cannot be configured must not keep its workspace
+            raise
         self.weights_loaded = False
         self.last_forward_scale = 16.0     # lowest activation scale any chunk of the last forward_* call needed
         self.forward_retries = 0           # tiles of the last forward_* call that were repeated at a lower activation scale
@@ -115,8 +121,14 @@ class Engine:
         if af is None:
             return None, AF_NONE
         if af_mode == AF_BATCH and n > self.max_batch:
-            per_tile = af.abs().sum(dim=tuple(range(1, af.dim())), dtype=torch.float32)
-            return (None, AF_NONE) if float(per_tile.double().sum()) < 1e-6 else (af, AF_ALWAYS)
+            # the library's own per-tile reduction (no |af| temporary of the batch's size), combined exactly as forward_impl combines
+            # it for MICA_AF_BATCH: f32 per-tile sums added in double - the same decision on either side of max_batch
+            sums = (C.c_float * n)()
+            self._check(self.lib.mica_af_abs_sums(self._h, _ptr(af), n, sums, self._stream()), "mica_af_abs_sums")
+            tot = 0.0
+            for v in sums:
+                tot += float(v)
+            return (None, AF_NONE) if tot < 1e-6 else (af, AF_ALWAYS)
         return af, af_mode
 
     def _cubic(self, what):

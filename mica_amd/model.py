@@ -10,9 +10,11 @@ from .weights import param_shapes
 
 
 class MICA:
-    def __init__(self, base_filters: int = 64, dropout_schedule=None, max_batch: int = 8, max_cached_shapes: int = 4):
-        """max_cached_shapes: engines (one per tile shape, each holding its own workspace: 37 GB at 8 tiles of 64^3) kept alive;
-        the least recently used one is closed when another shape arrives."""
+    def __init__(self, base_filters: int = 64, dropout_schedule=None, max_batch: int = 8, max_cached_shapes: int = 1):
+        """max_cached_shapes: engines (one per tile shape, each holding its own workspace: 37 GB at 8 tiles of 64^3, more for larger
+        boxes) kept alive; the least recently used one is closed when another shape arrives.  Default 1: the predictor feeds one tile
+        shape, and a caller that cycles through box shapes should not pin a workspace per shape without asking for it (a new shape
+        costs a workspace allocation and a weight upload + repack, ~0.1 s)."""
         if base_filters != 64:
             raise MicaHipError("only base_filters=64 (the reference default, model.py:261) is built")
         self.max_batch = max_batch

@@ -87,3 +87,27 @@ def stress_case(kind: str, S: int):
     else:
         raise ValueError(kind)
     return w, np.ascontiguousarray(x), np.ascontiguousarray(af)
+
+
+# The 64^3 single-tile cases that have a float64-truth fixture (tests/golden/truth64_S64_sub_<case>.npz, generator:
+# oracle/gen_golden_r5.py): case -> (weights seed, final gain, input seed) for uniform density + Bernoulli(1e-3) encodings.
+# The first four reuse the inputs of model_S64_*_sub*.npz; s101..s104 are four more input seeds of the weight set whose golden
+# sits closest to the 1e-4 bar.
+CASES64 = {
+    "w2022g6": (2022, 6.0, 31), "w7g3": (7, 3.0, 33), "w99g10": (99, 10.0, 33), "zeroaf_w2022g6": (2022, 6.0, 33),
+    "blob": None, "heavy": None,
+    "w99g10_s101": (99, 10.0, 101), "w99g10_s102": (99, 10.0, 102), "w99g10_s103": (99, 10.0, 103), "w99g10_s104": (99, 10.0, 104),
+}
+
+
+def case64(case: str):
+    """-> (weights dict, map float32 [1,1,64,64,64], AF3 encodings float32 [1,24,64,64,64]) of a CASES64 entry."""
+    from .weights import synth_state_dict
+    if case in ("blob", "heavy"):
+        return stress_case(case, 64)
+    wseed, gain, seed = CASES64[case]
+    x = synth_density((1, 1, 64, 64, 64), seed)
+    af = synth_af((64, 64, 64), seed, 1e-3)[None]
+    if case.startswith("zeroaf"):
+        af = np.zeros_like(af)
+    return synth_state_dict(wseed, gain), x, np.ascontiguousarray(af)

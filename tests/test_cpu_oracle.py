@@ -254,7 +254,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = _cabi.load_library()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mica_abi_version() == 1
+    assert lib.mica_abi_version() == _cabi.ABI_VERSION
     assert lib.mica_tile_count(512, 512, 512, 48) == 1331 and lib.mica_tile_count(256, 256, 256, 32) == 512
     assert lib.mica_tile_count(0, 1, 1, 48) < 0
 
@@ -462,3 +462,39 @@ def test_whole_network_winograd_emulation_supports_the_shipped_choice(golden_dir
     assert max(e32) < 1e-4 and max(e64) < 1e-4
     _, _, _, rms_all, _ = wn.run_case("f43", "w2022g6", "model_S16_af.npz", 2022, 6.0, golden_dir)
     assert rms_all > 1.3 * rms and rms < 1.5 * ref_rms
+
+
+def test_stale_library_is_refused_with_a_rebuild_message(monkeypatch):
+    """the library is git-ignored, so a checkout can meet an older build; the ABI version check says 'rebuild' instead of
+    failing later on a missing symbol or a changed struct."""
+    from mica_amd import _cabi
+    monkeypatch.setattr(_cabi, "ABI_VERSION", _cabi.ABI_VERSION + 1)
+    with pytest.raises(_cabi.MicaHipError, match="rebuild"):
+        _cabi.load_library(_cabi.LIB_PATH)
+
+
+def test_bench_refuses_counter_figures_of_other_sources(tmp_path, monkeypatch):
+    """bench.py quotes PMC traffic / MFMA-busy figures from committed profiles only when they were collected on the
+    library sources that are running (mica_amd/_cabi.py::source_hash, stamped by tools/profile.sh)."""
+    import bench
+    from mica_amd._cabi import source_hash
+    h = source_hash()
+    assert len(h) == 16 and h == source_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "r09_pmc_traffic.json").write_text(json.dumps({"library_source_hash": h, "kernels": {"conv_wino43_kernel": {"hbm_bytes": 5.0}}}))
+    (prof / "r09_pmc_sq_summary.txt").write_text(
+        "kernel                       calls     avg us clock GHz   mfma%  wait_any wait_inst    active  lds_act%  bank_cf% valu/wave-cyc\n"
+        "conv_wino43_kernel              20    12100.0      1.69    70.7     0.316     0.497     0.187      17.0      1.42      0.085\n"
+        "depthwise_kernel<4, 8>          15      593.7      1.98     0.0     0.355     0.219     0.426      37.9      1.17      0.283\n"
+        "mfma% = note line\nlibrary_source_hash: " + h + "\n")
+    t, note = bench.load_traffic(h, True)
+    assert t["conv_wino43_kernel"]["hbm_bytes"] == 5.0 and note == "r09_pmc_traffic.json"
+    sq, note = bench.load_sq_summary(h, True)
+    assert sq["conv_wino43_kernel"] == {"calls": 20.0, "avg_us": 12100.0, "clock_ghz": 1.69, "mfma_busy": 70.7 / 100.0}
+    assert sq["depthwise_kernel<4, 8>"]["avg_us"] == 593.7
+    t, note = bench.load_traffic("0" * 16, True)
+    assert t == {} and "REFUSED" in note
+    sq, note = bench.load_sq_summary("0" * 16, True)
+    assert sq == {} and "REFUSED" in note

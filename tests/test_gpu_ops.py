@@ -265,3 +265,83 @@ def test_forward_records_equal_forward_tiles(weights):
     e.forward_records(x, af, rec, af_mode=AF_PER_TILE)
     assert torch.equal(rec[:, 0], bbp) and torch.equal(rec[:, 1], cap) and torch.equal(rec[:, 2], pred) and torch.equal(rec[:, 3:], aap)
     e.close()
+
+
+# ---- ABI hygiene (include/mica_hip.h: "No entry point aborts the process"; box limits of the single-op entry points) -----------------
+def _op_calls(e, x1):
+    """One call per mica_op_* entry with the box (batch, d, h, w) left open: f(batch, d, h, w) -> return code.  The pointers are valid
+    but tiny: an entry that did not check its box before touching them would fault, which is what the test is for."""
+    import ctypes as C
+    from mica_amd import _cabi
+    lib, h, st = e.lib, e._h, e._stream()
+    p = C.c_void_p(x1.data_ptr())
+    w = np.zeros(1 << 16, np.float32).ctypes.data_as(_cabi._FP)
+    return {
+        "mica_op_conv3d": lambda b, d, hh, ww: lib.mica_op_conv3d(h, p, b, 16, d, hh, ww, w, w, 32, 3, p, st),
+        "mica_op_conv3d_variant(1)": lambda b, d, hh, ww: lib.mica_op_conv3d_variant(h, p, b, 16, d, hh, ww, w, w, 128, 3, 1, p, st),
+        "mica_op_norm_conv1_conv3": lambda b, d, hh, ww: lib.mica_op_norm_conv1_conv3(h, p, b, 16, d, hh, ww, w, w, 64, w, w, 32, p, st),
+        "mica_op_norm_conv1_conv3_variant(1)": lambda b, d, hh, ww: lib.mica_op_norm_conv1_conv3_variant(h, p, b, 16, d, hh, ww, w, w, 64, w, w, 128, 1, p, st),
+        "mica_op_instnorm_relu": lambda b, d, hh, ww: lib.mica_op_instnorm_relu(h, p, b, 16, d, hh, ww, p, st),
+        "mica_op_depthwise3": lambda b, d, hh, ww: lib.mica_op_depthwise3(h, p, b, 16, d, hh, ww, w, w, p, st),
+        "mica_op_se_depthwise": lambda b, d, hh, ww: lib.mica_op_se_depthwise(h, p, b, 32, d, hh, ww, w, w, w, w, w, w, p, st),
+        "mica_op_stem": lambda b, d, hh, ww: lib.mica_op_stem(h, p, b, d, hh, ww, p, st),
+    }
+
+
+def test_single_op_entries_refuse_oversized_boxes(eng):
+    """the exported single-op calls did not bound d, h, w - a large box reached an abort() in a launch helper or
+    overflowed the kernels' 32-bit slab offsets.  Every entry now answers MICA_ERR_ARG (and says why) for an edge beyond 128, an edge
+    below 1 or more than 64 tiles, before it allocates or launches anything; the context stays usable."""
+    from mica_amd import _cabi
+    x1 = torch.zeros(64, device="cuda")
+    calls = _op_calls(eng, x1)
+    for name, f in calls.items():
+        for box in ((1, 129, 8, 8), (1, 8, 4096, 8), (1, 8, 8, 1 << 20), (65, 8, 8, 8), (1, 0, 8, 8), (1, 8, 8, -3)):
+            rc = f(*box)
+            assert rc == _cabi.MICA_ERR_ARG, (name, box, rc)
+            msg = eng.lib.mica_last_error(eng._h).decode()
+            assert "box limits" in msg or "bad argument" in msg, (name, msg)
+    # still healthy
+    x = _rand((1, 16, 8, 8, 8), 5)
+    w = _rand((32, 16, 3, 3, 3), 6) * 0.1
+    assert rel_err(eng.op_conv3d(x.cuda(), w.numpy(), np.zeros(32, np.float32), 3), F.conv3d(x, w, None, padding=1)) < RTOL
+
+
+def test_a_pending_host_hip_error_is_neither_consumed_nor_launched_behind(eng):
+    """MICA_ENTER used to call hipGetLastError() and so swallowed an error of the HOST program pending on the thread.  Now
+    a call made behind such an error returns MICA_ERR_STATE without launching, and the error is still there for the host."""
+    import ctypes as C
+    from mica_amd import _cabi
+    hip = None
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        try:
+            hip = C.CDLL(name)            # already mapped by torch: dlopen hands back the process's copy
+            break
+        except OSError:
+            continue
+    if hip is None:
+        pytest.skip("libamdhip64 not loadable by name")
+    hip.hipGetLastError.restype = C.c_int
+    hip.hipPeekAtLastError.restype = C.c_int
+    torch.cuda.synchronize()
+    hip.hipGetLastError()
+    bad = C.c_void_p()
+    assert hip.hipMalloc(C.byref(bad), C.c_size_t(1 << 60)) != 0          # the host program's own failure: sets the sticky last error
+    if hip.hipPeekAtLastError() == 0:
+        pytest.skip("this runtime copy does not share torch's error state")
+    x = _rand((1, 16, 8, 8, 8), 5).cuda()
+    y = torch.empty_like(x)
+    rc = eng.lib.mica_op_instnorm_relu(eng._h, C.c_void_p(x.data_ptr()), 1, 16, 8, 8, 8, C.c_void_p(y.data_ptr()), eng._stream())
+    assert rc == _cabi.MICA_ERR_STATE and "pending" in eng.lib.mica_last_error(eng._h).decode()
+    assert hip.hipGetLastError() != 0                                     # the host still finds its error ...
+    assert hip.hipGetLastError() == 0                                     # ... once
+    got = eng.op_instnorm_relu(x)                                         # and the library works again
+    assert rel_err(got, F.relu(F.instance_norm(x.cpu()))) < RTOL
+
+
+def test_engine_refuses_a_bad_conv_variant_before_it_allocates():
+    from mica_amd.engine import Engine, MicaHipError
+    free0 = torch.cuda.mem_get_info(0)[0]
+    with pytest.raises(MicaHipError, match="conv_variant"):
+        Engine(0, max_batch=2, tile_size=64, conv_variant=3)
+    assert torch.cuda.mem_get_info(0)[0] >= free0 - (64 << 20)
