@@ -169,6 +169,10 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="with --gpus 1: a process group of ONE rank whose record exchange still runs the collective "
                          "(--backend nccl executes the RCCL all_gather_into_tensor(async_op=True) branch on one GPU)")
+    ap.add_argument("--af-f32", action="store_true", help="keep the AF3 encodings resident as float32 (default: uint8, a quarter of the bytes)")
+    ap.add_argument("--gather-to-root", action="store_true",
+                    help="N>1 / --force-exchange: bring the records to the stitching rank alone (dist.gather) instead of the all-gather "
+                         "BASELINE.json's north_star names")
     ap.add_argument("--strong", action="store_true",
                     help="strong-scaling mode: ONE complete map, every window, sharded over the ranks (predict_volume_sharded), rank-0 "
                          "stitch and the final D2H of the four volumes inside the clock; --steps/--warmup are ignored")
@@ -229,9 +233,11 @@ def main():
     if not args.no_af:
         # 24 binary channels with ~1e-3 occupancy, generated on the device channel by channel
         g = torch.Generator(device=dev).manual_seed(2001)
-        af = torch.empty((24, n, n, n), dtype=torch.float32, device=dev)
+        # resident as uint8 (the encodings are binary, preprocessing.py:288-298): 3.2 GB instead of 12.9 GB at 512^3 on every rank;
+        # mica_gather_tiles_u8 hands the network the same float32 tiles
+        af = torch.empty((24, n, n, n), dtype=torch.float32 if args.af_f32 else torch.uint8, device=dev)
         for c in range(24):
-            af[c] = (torch.rand((n, n, n), generator=g, device=dev) < 1e-3).float()
+            af[c] = (torch.rand((n, n, n), generator=g, device=dev) < 1e-3).to(af.dtype)
     weights = synth_state_dict(2022)
     S = args.grid + 2 * args.pad
     eng = Engine(local, max_batch=B, tile_size=S)
@@ -249,7 +255,7 @@ def main():
     if grouped:
         # cropped records carry no halo: stitched with pad 0 on a grid-sized window
         ex = RecordExchange(B, (23, g3, g3, g3), dev, lambda rec, first: eng.stitch_tiles(rec, out, g3, 0, first), stitch_rank=0,
-                            force_collective=args.force_exchange)
+                            force_collective=args.force_exchange, gather_to_root=args.gather_to_root)
 
     def step(k, pred=vp, grid=g3, pad=p):
         rec = pred.run_batch(vol, af, first_of(k, rank), B)
@@ -272,13 +278,16 @@ def main():
         sync()
         del out
         out = None
-        host = torch.empty((23, n, n, n), dtype=torch.float32).pin_memory() if rank == 0 else None
         sync()
         t0 = time.perf_counter()
         stats = {}
-        vols = vp.predict_volume_sharded(vol, af, force_collective=args.force_exchange, stats=stats) if grouped else vp.predict_volume(vol, af)
-        if rank == 0:
-            host.copy_(vols["backbone_probability"]._base, non_blocking=True)
+        # the four volumes reach the host slab by slab while later tiles compute (pipeline.py::SlabDownloader, pinned buffer
+        # allocated beside the first slab's compute): what is left behind the last tile is one x slab, not 12.3 GB
+        if grouped:
+            vols = vp.predict_volume_sharded(vol, af, force_collective=args.force_exchange, stats=stats, to_host=True,
+                                             gather_to_root=args.gather_to_root)
+        else:
+            vols = vp.predict_volume(vol, af, to_host=True)
         sync()
         dt = time.perf_counter() - t0
         if grouped:
@@ -286,7 +295,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         if rank == 0:
-            chk = float(host[3:, ::16, ::16, ::16].sum(dim=0).sub(1).abs().max())
+            chk = float(abs(vols["amino_acid_probability"][:, ::16, ::16, ::16].sum(axis=0) - 1).max())
             rounds = (T + B * world - 1) // (B * world)
             emit({
                 "metric": "64^3 sub-grids/sec", "value": T / dt, "unit": "sub-grids/s", "n_gpus": world, "steps": rounds, "warmup": 1,
@@ -294,8 +303,8 @@ def main():
                 "dtype": "f32 (3x f16 MFMA split products, f32 accumulate)", "data": "synthetic",
                 "config": {"workload": f"ONE complete synthetic {n}^3 density map + 24-ch AF3 encodings, every one of its {T} windows (64 = grid "
                                        f"{args.grid} + 2x{args.pad} halo) sharded over {world} rank(s), gather+forward+softmax, "
-                                       + (f"{'RCCL' if args.backend == 'nccl' else args.backend} all-gather of cropped records, " if grouped else "")
-                                       + "rank-0 stitch and the D2H of the four volumes (12.3 GB at 512^3) inside the clock",
+                                       + (f"{'RCCL' if args.backend == 'nccl' else args.backend} {stats.get('collective', 'all_gather')} of cropped records, " if grouped else "")
+                                       + "rank-0 stitch and the D2H of the four volumes (12.3 GB at 512^3; slab by slab behind the stitch) inside the clock",
                            "backend": args.backend if grouped else None, "tiles": T, "seconds_per_map": dt, "collectives": stats.get("collectives"),
                            "softmax_sum_check": chk, "af_path": not args.no_af}})
         if grouped:
@@ -453,11 +462,12 @@ def main():
             "config": {"workload": f"synthetic {n}^3 density map + 24-ch AF3 encodings, window 64 = grid {args.grid} + 2x{args.pad} halo, "
                                    f"{T} tiles per map, {B} tiles per step per GPU, gather+forward+softmax+stitch"
                                    + ("" if not grouped else f", {'RCCL' if args.backend == 'nccl' else args.backend + ' (rehearsal, host-staged)'} "
-                                      "all-gather of cropped records to every rank, rank 0 stitches"
+                                      + ("gather of cropped records into rank 0, which stitches" if args.gather_to_root else "all-gather of cropped records to every rank, rank 0 stitches")
                                       + (f" (collective forced in a group of one rank; {ex.collectives} all-gathers issued)" if world == 1 else ""))
                                    + (", every rank on cuda:0" if args.single_device else ""),
                        "backend": args.backend if grouped else None,
-                       "tiles_per_step": B * world, "af_path": not args.no_af, "flops_per_tile": FLOPS_PER_TILE_AF,
+                       "tiles_per_step": B * world, "af_path": not args.no_af, "encodings_resident_as": None if af is None else str(af.dtype).replace("torch.", ""),
+                       "flops_per_tile": FLOPS_PER_TILE_AF,
                        "seconds_per_map": T / value},
             "sustained": None if whole is None else {
                 "value": whole["value"], "unit": "sub-grids/s", "seconds": whole["predict_seconds"], "tiles": whole["tiles"],

@@ -53,10 +53,10 @@ def main(argv=None) -> int:
         enc = dp.encode_AF3_volume(args.docked_model, hd.origin, norm.shape)            # [24, nz, ny, nx] on the device
         perm = _axis_perm(hdn)
         d_af = enc.permute(0, *[1 + p for p in perm]).contiguous()
-    vols = VolumePredictor(eng, args.grid_size, args.padding, args.batch).predict_volume(d_vol, d_af)
+    vols = VolumePredictor(eng, args.grid_size, args.padding, args.batch).predict_volume(d_vol, d_af, to_host=True)
     os.makedirs(args.out, exist_ok=True)
     for k, v in vols.items():
-        np.save(os.path.join(args.out, f"{k}.npy"), v.cpu().numpy())
+        np.save(os.path.join(args.out, f"{k}.npy"), v)
     T = int(eng.lib.mica_tile_count(*d_vol.shape, args.grid_size))
     print(f"map {tuple(data.shape)} -> {tuple(d_vol.shape)} (x, y, z), median {med:.6g}, 99.9th percentile {pct:.6g}, offset {offset}, "
           f"{T} sub-grids, {time.time() - t0:.1f} s; volumes in {args.out}")

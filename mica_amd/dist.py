@@ -44,7 +44,7 @@ class RecordExchange:
     the host, synchronously."""
 
     def __init__(self, batch: int, rec_shape, device, stitch, dtype=torch.float32, group=None, stitch_rank: int | None = 0,
-                 force_collective: bool = False):
+                 force_collective: bool = False, gather_to_root: bool = False):
         self.group = group
         on = dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
@@ -55,9 +55,14 @@ class RecordExchange:
         # force_collective: take the collective path even in a group of ONE rank - the way to execute the RCCL branch
         # (device tensors, async_op, work.wait() ordering, slot reuse) on a box with a single GPU
         self.collective = self.world > 1 or (force_collective and on)
+        # gather_to_root: only the stitching rank consumes the records, so only it needs them: `dist.gather` (RCCL: grouped
+        # send / recv into the root) instead of the all-gather BASELINE.json's north_star names - the same bytes into rank 0 over
+        # its seven xGMI links, no traffic between the other ranks, and receive buffers on one rank instead of eight
+        self.to_root = bool(gather_to_root) and stitch_rank is not None
+        self.root = dist.get_global_rank(group, stitch_rank) if (self.to_root and on and group is not None) else (stitch_rank or 0)
         self.send = [torch.zeros((batch, *rec_shape), dtype=dtype, device=device) for _ in range(2)]
         self.recv = None
-        if self.collective:
+        if self.collective and (not self.to_root or self.rank == stitch_rank):
             # one flat receive buffer per slot: [world * batch, ...]; rank rr's records are rows rr*batch ...
             self.recv = [torch.empty((self.world * batch, *rec_shape), dtype=dtype, device=device) for _ in range(2)]
         self.pending = None
@@ -68,10 +73,19 @@ class RecordExchange:
             return None
         self.collectives += 1
         if self.backend == "gloo" and self.device.type == "cuda":      # rehearsal of N > 1 on a GPU without RCCL: through the host
+            if self.to_root:
+                host = [torch.empty(self.send[slot].shape, dtype=self.send[slot].dtype) for _ in range(self.world)] if self.recv is not None else None
+                dist.gather(self.send[slot].cpu(), gather_list=host, dst=self.root, group=self.group)
+                if host is not None:
+                    self.recv[slot].copy_(torch.cat(host))
+                return None
             host = torch.empty(self.recv[slot].shape, dtype=self.recv[slot].dtype)
             dist.all_gather_into_tensor(host, self.send[slot].cpu(), group=self.group)
             self.recv[slot].copy_(host)
             return None
+        if self.to_root:
+            parts = list(self.recv[slot].split(self.batch)) if self.recv is not None else None
+            return dist.gather(self.send[slot], gather_list=parts, dst=self.root, group=self.group, async_op=True)
         # the same call with RCCL (device tensors, asynchronous on the collective's stream) and in the CPU tests (gloo)
         return dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
 
@@ -101,7 +115,8 @@ class RecordExchange:
 
 
 def sharded_records(run_batch, stitch, T: int, batch: int, rec_shape, device, dtype=torch.float32, group=None,
-                    stitch_rank: int | None = 0, force_collective: bool = False, stats: dict | None = None):
+                    stitch_rank: int | None = 0, force_collective: bool = False, stats: dict | None = None,
+                    gather_to_root: bool = False):
     """run_batch(first, count) -> tensor [count, *rec_shape] on `device`;
     stitch(records [count, *rec_shape], first) is called on `stitch_rank` (None = every rank) for every
     batch of every rank, in global tile order within a round."""
@@ -113,7 +128,7 @@ def sharded_records(run_batch, stitch, T: int, batch: int, rec_shape, device, dt
         stitch(rec, first)
 
     ex = RecordExchange(batch, rec_shape, device, counted, dtype=dtype, group=group, stitch_rank=stitch_rank,
-                        force_collective=force_collective)
+                        force_collective=force_collective, gather_to_root=gather_to_root)
     mine, rounds = rank_batches(T, batch, ex.rank, ex.world)
     for r, first, count in mine:
         layout = [plan[r * ex.world + rr] if r * ex.world + rr < len(plan) else (0, 0) for rr in range(ex.world)]
@@ -125,5 +140,6 @@ def sharded_records(run_batch, stitch, T: int, batch: int, rec_shape, device, dt
         if seen != dict(plan):
             raise RuntimeError(f"sharded_records: stitched batches {sorted(seen.items())} != plan {plan}")
     if stats is not None:
-        stats.update(collectives=ex.collectives, backend=ex.backend, world=ex.world, rounds=rounds)
+        stats.update(collectives=ex.collectives, backend=ex.backend, world=ex.world, rounds=rounds,
+                     collective="gather" if ex.to_root else "all_gather")
     return rounds

@@ -48,6 +48,8 @@ class MrcHeader:
 
 def read_mrc(path: str):
     """-> (data ndarray [nz,ny,nx] in file dtype, MrcHeader)."""
+    from . import handoff
+    handoff.wait_file(path)                  # a file a stage of this process is still writing in the background: join its writer
     with open(path, "rb") as f:
         h = f.read(1024)
         if len(h) < 1024:

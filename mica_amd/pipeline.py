@@ -15,6 +15,58 @@ from .engine import AF_PER_TILE, Engine
 KEYS = ("backbone_probability", "carbon_alpha_probability", "amino_acid_prediction", "amino_acid_probability")
 
 
+def volume_dict(full):
+    """The four volumes of utils/predict.py:459-462 as views of one [23, N0, N1, N2] array / tensor (record channel order)."""
+    return {"backbone_probability": full[0], "carbon_alpha_probability": full[1], "amino_acid_prediction": full[2],
+            "amino_acid_probability": full[3:]}
+
+
+class SlabDownloader:
+    """Brings the stitched volumes to the host WHILE the map is still being computed.
+
+    Tiles are processed in the reference's order (utils/create_grids.py:143-145: x outermost), so once the tiles of an x block
+    have been stitched the slab out[:, i:i+grid] is final: its 23 channel pieces (each contiguous) are copied into a pinned host
+    buffer on a copy stream behind an event of the stitching stream.  What is left when the last tile is done is the last slab
+    only - at 512^3, 1.1 of 12.3 GB.  The pinned buffer is allocated on a helper thread (page-locking 12 GB takes longer than the
+    first slab needs to compute)."""
+
+    def __init__(self, out: torch.Tensor, grid: int, tiles_per_slab: int):
+        import threading
+        self.out, self.grid, self.per = out, grid, tiles_per_slab
+        self.n0 = out.shape[1]
+        self.nslabs = -(-self.n0 // grid)
+        self.stream = torch.cuda.Stream(device=out.device)
+        self.next = 0
+        self.host = None
+
+        def alloc():
+            self.host = torch.empty(out.shape, dtype=out.dtype).pin_memory()
+        self._alloc = threading.Thread(target=alloc, name="mica-pinned-alloc")
+        self._alloc.start()
+
+    def tiles_done(self, n_tiles: int):
+        """`n_tiles` tiles (in table order) have been stitched on the current stream: download every slab they complete."""
+        complete = min(n_tiles // self.per, self.nslabs)
+        if complete <= self.next:
+            return
+        if self.host is None:
+            self._alloc.join()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.out.device))
+        lo, hi = self.next * self.grid, min(complete * self.grid, self.n0)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            for c in range(self.out.shape[0]):
+                self.host[c, lo:hi].copy_(self.out[c, lo:hi], non_blocking=True)
+        self.next = complete
+
+    def finish(self) -> torch.Tensor:
+        """-> the pinned host tensor [23, N0, N1, N2], complete."""
+        self.tiles_done(self.per * self.nslabs)
+        self.stream.synchronize()
+        return self.host
+
+
 class VolumePredictor:
     def __init__(self, engine: Engine, grid_size: int = 48, padding: int = 8, batch: int | None = None):
         if grid_size + 2 * padding != engine.tile_size:
@@ -39,19 +91,24 @@ class VolumePredictor:
         S = e.tile_size
         return e.forward_records(mt.view(count, S, S, S), at, self._rec[:count], af_mode=AF_PER_TILE)
 
-    def predict_volume(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None):
-        """vol f32[N0,N1,N2] on the GPU (already normalised, (x,y,z) order), af_vol f32[24,N0,N1,N2] or None.
-        Returns the dict of four device volumes with the shapes/dtypes of utils/predict.py:459-462."""
+    def predict_volume(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None, to_host: bool = False):
+        """vol f32[N0,N1,N2] on the GPU (already normalised, (x,y,z) order), af_vol f32 or uint8 [24,N0,N1,N2] or None.
+        Returns the dict of four device volumes with the shapes/dtypes of utils/predict.py:459-462 - or, with `to_host`, the same
+        dict as numpy arrays (views of one pinned buffer), downloaded slab by slab while later tiles compute (SlabDownloader)."""
         e = self.e
         n0, n1, n2 = vol.shape
         T = int(e.lib.mica_tile_count(n0, n1, n2, self.grid))
         out = torch.zeros((23, n0, n1, n2), dtype=torch.float32, device=e.device)
+        dl = SlabDownloader(out, self.grid, (-(-n1 // self.grid)) * (-(-n2 // self.grid))) if to_host else None
         for first in range(0, T, self.batch):
             count = min(self.batch, T - first)
             rec = self.run_batch(vol, af_vol, first, count)
             e.stitch_tiles(rec, out, self.grid, self.pad, first)
-        return {"backbone_probability": out[0], "carbon_alpha_probability": out[1],
-                "amino_acid_prediction": out[2], "amino_acid_probability": out[3:]}
+            if dl is not None:
+                dl.tiles_done(first + count)
+        if dl is not None:
+            return volume_dict(dl.finish().numpy())
+        return volume_dict(out)
 
     def predict_maps_streamed(self, maps, afs=None):
         """Several independent maps back to back (BASELINE.json configs[4]) with host buffers on both sides.
@@ -140,11 +197,14 @@ class VolumePredictor:
         return results
 
     def predict_volume_sharded(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None, group=None,
-                               force_collective: bool = False, stats: dict | None = None):
-        """Multi-GPU form: every rank holds the (normalised) volume, runs its share of the tile batches and
-        the cropped records are all-gathered (RCCL); rank 0 returns the dict, the other ranks return None.
-        force_collective: run the all-gather even in a process group of one rank (executes the RCCL branch on one GPU);
-        stats (optional dict) receives the number of collectives issued, the backend and the world size."""
+                               force_collective: bool = False, stats: dict | None = None, to_host: bool = False,
+                               gather_to_root: bool = False):
+        """Multi-GPU form: every rank holds the (normalised) volume (the encodings as uint8: a quarter of the bytes on every rank),
+        runs its share of the tile batches and the cropped records are all-gathered (RCCL) - or, with `gather_to_root`, gathered into
+        the stitching rank alone; rank 0 returns the dict, the other ranks return None.
+        force_collective: run the collective even in a process group of one rank (executes the RCCL branch on one GPU);
+        stats (optional dict) receives the number of collectives issued, the backend and the world size;
+        to_host: rank 0 returns numpy arrays, downloaded slab by slab while later rounds compute (SlabDownloader)."""
         import torch.distributed as dist
         from .dist import sharded_records
         e = self.e
@@ -157,12 +217,20 @@ class VolumePredictor:
         def run(first, count):
             return self.run_batch(vol, af_vol, first, count)[:, :, p:p + g, p:p + g, p:p + g]
 
+        dl = SlabDownloader(out, g, (-(-n1 // g)) * (-(-n2 // g))) if to_host and rank == 0 else None
+        done = [0]
+
         def stitch(rec, first):
             e.stitch_tiles(rec.contiguous(), out, g, 0, first)      # cropped records: window = grid, no halo
+            if dl is not None:
+                # batches reach the stitcher in tile order (round by round, rank by rank): everything before first + count is final
+                done[0] = max(done[0], first + int(rec.shape[0]))
+                dl.tiles_done(done[0])
 
         sharded_records(run, stitch, T, self.batch, (23, g, g, g), e.device, group=group, stitch_rank=0,
-                        force_collective=force_collective, stats=stats)
+                        force_collective=force_collective, stats=stats, gather_to_root=gather_to_root)
         if rank != 0:
             return None
-        return {"backbone_probability": out[0], "carbon_alpha_probability": out[1],
-                "amino_acid_prediction": out[2], "amino_acid_probability": out[3:]}
+        if dl is not None:
+            return volume_dict(dl.finish().numpy())
+        return volume_dict(out)

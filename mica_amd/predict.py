@@ -13,6 +13,7 @@ import time
 import numpy as np
 import torch
 
+from . import handoff
 from .dataset import CryoEMTestDataset
 from .engine import AF_BATCH, AF_PER_TILE, Engine
 from .weights import load_checkpoint_state_dict
@@ -43,6 +44,8 @@ class CryoEMPredictor:
         self.loader_threads = 4             # tile-file readers beside the GPU: 66.0 sub-grids/s with 4, 55.1 with 2 (profiles/r04_file_predictor.txt)
         self.use_optimized_batching = False
         self.optimal_batch_size = 1
+        self.use_resident_volumes = True    # take the volumes a GridCreator of this process left on the GPU (handoff.py) instead of its files
+        self.resident = None                # (map entry, AF3 entry or None) once select_processing_strategy found them
         self.engine = None
         self.sample_count = 0
         self.timing_stats = {k: 0 for k in ('strategy_selection', 'model_loading', 'data_loading', 'inference',
@@ -53,9 +56,44 @@ class CryoEMPredictor:
         if not self.quiet:
             print(m)
 
+    # ---- the in-process hand-off ---------------------------------------------------------------------------
+    def _find_resident(self):
+        """(map entry, AF3 entry or None) when the `GridCreator` mirror of THIS process cut `grids_path` and its volumes are still on
+        the GPU (mica_amd/handoff.py); None -> the tile files are read, as the reference does.  `reference_batching` always reads the
+        files: its batches are runs of FILES in glob order (utils/predict.py:278-286)."""
+        if not self.use_resident_volumes or self.reference_batching:
+            return None
+        m = handoff.lookup_grids(os.path.join(self.grids_path, "normalized_map_grids"))
+        if m is None or m.kind != "map":
+            return None
+        afdir = os.path.join(self.grids_path, "AF3_encoding_grids")
+        a = handoff.lookup_grids(afdir)
+        if a is not None and (a.kind != "af3" or a.shape != m.shape or (a.grid_size, a.padding) != (m.grid_size, m.padding)):
+            a = None
+        if a is None and os.path.isdir(afdir) and glob.glob(os.path.join(afdir, "*_grids", "*.npz")):
+            return None                      # encodings tiled by somebody else: their files are the only copy
+        return m, a
+
+    def _wait_for_tile_files(self):
+        """Before the files under grids_path are read: join the background writers of this process that are still producing them."""
+        for d in ("normalized_map_grids", "AF3_encoding_grids"):
+            e = handoff.lookup_grids(os.path.join(self.grids_path, d))
+            if e is not None and e.writer is not None:
+                e.writer.wait()
+
     # ---- steps (names as in the reference) ----------------------------------------------------------
     def select_processing_strategy(self):
         t0 = time.time()
+        self.resident = self._find_resident()
+        if self.resident is not None:
+            from ._cabi import tile_table
+            m = self.resident[0]
+            self.sample_count = len(tile_table(*m.shape, m.grid_size))
+            self.use_optimized_batching = self.sample_count > self.batch_threshold
+            self.optimal_batch_size = 8 if self.use_optimized_batching else 1
+            self.timing_stats['strategy_selection'] = time.time() - t0
+            return True
+        self._wait_for_tile_files()
         files = glob.glob(f"{self.grids_path}/normalized_map_grids/*.npz")
         self.sample_count = len(files)
         self.timing_stats['strategy_selection'] = time.time() - t0
@@ -68,8 +106,10 @@ class CryoEMPredictor:
         self.optimal_batch_size = 8 if self.use_optimized_batching else 1
         return True
 
-    def load_model(self, tile_size=64):
+    def load_model(self, tile_size=None):
         t0 = time.time()
+        if tile_size is None:
+            tile_size = self.resident[0].grid_size + 2 * self.resident[0].padding if self.resident is not None else 64
         try:
             if not os.path.exists(self.model_path):
                 self.logger.error(f"Model file not found: {self.model_path}")
@@ -112,6 +152,8 @@ class CryoEMPredictor:
             order = sorted(range(len(meta)), key=lambda t: ((meta[t][0] // grid) * nt1 + meta[t][1] // grid) * nt2 + meta[t][2] // grid)
             tindex = lambda t: ((meta[t][0] // grid) * nt1 + meta[t][1] // grid) * nt2 + meta[t][2] // grid
             out = torch.zeros((23, *shape), dtype=torch.float32, device=e.device)
+            from .pipeline import SlabDownloader, volume_dict
+            dl = SlabDownloader(out, grid, nt1 * nt2)        # finished x slabs travel to the host while later tiles compute
             B = e.max_batch
             rec = torch.empty((B, 23, S, S, S), dtype=torch.float32, device=e.device)
             pos = 0
@@ -184,11 +226,29 @@ class CryoEMPredictor:
                     n = len(run)
                     e.forward_records(x.view(n, S, S, S), af, rec[:n], af_mode=AF_PER_TILE)
                     e.stitch_tiles(rec[:n], out, grid, pad, tindex(run[0]))
+                    dl.tiles_done(tindex(run[-1]) + 1)       # runs come in table order: every tile before this index that exists is done
                     x.record_stream(main_stream)
                     if af is not None:
                         af.record_stream(main_stream)
-            vols = {"backbone_probability": out[0].cpu().numpy(), "carbon_alpha_probability": out[1].cpu().numpy(),
-                    "amino_acid_prediction": out[2].cpu().numpy(), "amino_acid_probability": out[3:].cpu().numpy()}
+            vols = volume_dict(dl.finish().numpy())
+            self.timing_stats['inference'] = time.time() - t0
+            return vols
+        except Exception as e:
+            self.logger.error(f"Inference failed: {e}")
+            self.timing_stats['inference'] = time.time() - t0
+            return None
+
+    def run_inference_resident(self):
+        """The hot loop on the volumes GridCreator left on the GPU: gather -> forward -> softmax / argmax -> stitch per batch of
+        tiles, per-tile AF3 gating (= the reference at batch size 1 and = the file route of this class), the four volumes
+        downloaded slab by slab while later tiles compute.  A directory without encodings, or with fewer than the 24 channels,
+        means zeros for every tile (dataset/dataset.py:218-219) = the exp_downsizing branch."""
+        t0 = time.time()
+        try:
+            from .pipeline import VolumePredictor
+            m, a = self.resident
+            af = a.volume if a is not None and len(a.channels) == 24 else None
+            vols = VolumePredictor(self.engine, m.grid_size, m.padding, self.engine.max_batch).predict_volume(m.volume, af, to_host=True)
             self.timing_stats['inference'] = time.time() - t0
             return vols
         except Exception as e:
@@ -203,10 +263,19 @@ class CryoEMPredictor:
                 return False, {}
             if not self.load_model():
                 return False, {}
-            ok, dataset = self.prepare_data()
-            if not ok:
-                return False, {}
-            vols = self.run_inference(dataset)
+            if self.resident is not None:
+                vols = self.run_inference_resident()
+                # the tile files the caller asked GridCreator for are complete when this returns (utils/modeler.py:755 deletes
+                # grids_path right after nnPred: nothing may still be writing into it)
+                for e in self.resident:
+                    if e is not None and e.writer is not None:
+                        handoff._join(e.writer)
+                handoff.flush()              # ... nor into the normalised map / the encodings, which it deletes as well (:756-757)
+            else:
+                ok, dataset = self.prepare_data()
+                if not ok:
+                    return False, {}
+                vols = self.run_inference(dataset)
             if vols is None:
                 return False, {}
             if self.save_output:

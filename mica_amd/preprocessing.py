@@ -15,7 +15,7 @@ import os
 import numpy as np
 import torch
 
-from . import mrc
+from . import handoff, mrc
 from .engine import Engine, MicaHipError
 
 
@@ -39,6 +39,11 @@ class DataPreprocessor:
     def normalize_array(self, data: np.ndarray, voxel_size=(1.0, 1.0, 1.0), target_voxel_size=1.0):
         """preprocessing.py:111-133 on an array: returns (float32 map in [0,1], median, percentile).
         Raises MicaHipError where the reference logs 'Normalization failed'."""
+        t, med, pct = self.normalize_on_device(data, voxel_size, target_voxel_size)
+        return t.cpu().numpy(), med, pct
+
+    def normalize_on_device(self, data: np.ndarray, voxel_size=(1.0, 1.0, 1.0), target_voxel_size=1.0):
+        """The same, the result left on the GPU: (float32 device tensor [nz', ny', nx'], median, percentile)."""
         zf = [voxel_size[0] / target_voxel_size, voxel_size[1] / target_voxel_size, voxel_size[2] / target_voxel_size]
         eng = self._engine or Engine(self._device, max_batch=1, tile_size=64)
         self._engine = eng
@@ -53,18 +58,30 @@ class DataPreprocessor:
         # (identity on finite data, NaN spreading through the recursive prefilter otherwise)
         t = eng.zoom_cubic(t, zf, map_type)
         med, pct = eng.normalise_map_(t, map_type)
-        return t.cpu().numpy(), med, pct
+        return t, med, pct
 
     def resample_and_normalize_map(self, target_voxel_size=1.0):
         """Side effect and messages as preprocessing.py:80-170; returns None."""
         success = False
         try:
             data, hd = mrc.read_mrc(self.map_path)
-            out, _, _ = self.normalize_array(np.asarray(data), hd.voxel_size, target_voxel_size)
-            self.normalized_map_path = os.path.join(os.path.dirname(self.AF3_results), 'resampled_normalized_map.mrc')
-            mrc.write_mrc(self.normalized_map_path, out.astype(np.float32),
-                          voxel_size=(target_voxel_size,) * 3, origin=hd.origin, mapc=hd.mapc, mapr=hd.mapr, maps=hd.maps,
-                          nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart)
+            t, _, _ = self.normalize_on_device(np.asarray(data), hd.voxel_size, target_voxel_size)
+            self.normalized_map_path = path = os.path.join(os.path.dirname(self.AF3_results), 'resampled_normalized_map.mrc')
+            nz, ny, nx = (int(v) for v in t.shape)
+            tv = float(target_voxel_size)
+            # the header the written file will carry (mrc.write_mrc below), for the stage that takes the map from the GPU instead
+            hdn = mrc.MrcHeader(nx=nx, ny=ny, nz=nz, mode=2, nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart, mx=nx, my=ny, mz=nz,
+                                cella=(float(np.float32(nx * tv)), float(np.float32(ny * tv)), float(np.float32(nz * tv))),
+                                mapc=hd.mapc, mapr=hd.mapr, maps=hd.maps, origin=tuple(float(np.float32(v)) for v in hd.origin))
+
+            def write():
+                mrc.write_mrc(path, t.cpu().numpy(), voxel_size=(target_voxel_size,) * 3, origin=hd.origin, mapc=hd.mapc, mapr=hd.mapr,
+                              maps=hd.maps, nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart)
+            # the normalised map stays on the GPU for GridCreator (mica_amd/handoff.py); the file the reference's call site expects
+            # (utils/modeler.py:684-690) is written behind the caller's back and joined by whoever reads it
+            if os.path.exists(path):
+                os.remove(path)
+            handoff.register_file(path, t, hdn, writer=write)
             success = True
         except Exception as e:
             self.logger.error(f"Map processing failed: {e}")
@@ -86,14 +103,32 @@ class DataPreprocessor:
 
         success = False
         try:
-            data, hd = mrc.read_mrc(self.normalized_map_path)
-            vol = self.encode_AF3_volume(combined_docked_model_path, hd.origin, data.shape).cpu().numpy()
+            fe = handoff.lookup_file(self.normalized_map_path)
+            if fe is not None:
+                hd, shape = fe.header, tuple(fe.tensor.shape)
+            else:
+                handoff.wait_file(self.normalized_map_path)
+                data, hd = mrc.read_mrc(self.normalized_map_path)
+                shape = data.shape
+            vol = self.encode_AF3_volume(combined_docked_model_path, hd.origin, shape)          # f32 [24, nz, ny, nx] on the device
+            u8 = vol.to(torch.uint8)                                                            # 0 / 1 by construction (:288-298)
+            del vol
             self.AF3_encodings = os.path.join(os.path.dirname(self.AF3_results), 'AF3_encodings')
             os.makedirs(self.AF3_encodings, exist_ok=True)
+            nz, ny, nx = shape
+            hdn = mrc.MrcHeader(nx=nx, ny=ny, nz=nz, mode=2, nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart, mx=nx, my=ny, mz=nz,
+                                cella=(float(nx), float(ny), float(nz)), mapc=hd.mapc, mapr=hd.mapr, maps=hd.maps,
+                                origin=tuple(float(np.float32(v)) for v in hd.origin))
+            # the 24 channel files are written in the background, each channel staying resident (uint8) for GridCreator
             for ch, name in enumerate(af3_encoding.CHANNEL_NAMES):
-                mrc.write_mrc(os.path.join(self.AF3_encodings, f"{name}_encoding.mrc"), vol[ch], voxel_size=(1.0, 1.0, 1.0),
-                              origin=hd.origin, mapc=hd.mapc, mapr=hd.mapr, maps=hd.maps, nxstart=hd.nxstart,
-                              nystart=hd.nystart, nzstart=hd.nzstart)
+                p = os.path.join(self.AF3_encodings, f"{name}_encoding.mrc")
+                if os.path.exists(p):
+                    os.remove(p)
+
+                def write(p=p, ch=ch):
+                    mrc.write_mrc(p, u8[ch].cpu().numpy().astype(np.float32), voxel_size=(1.0, 1.0, 1.0), origin=hd.origin, mapc=hd.mapc,
+                                  mapr=hd.mapr, maps=hd.maps, nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart)
+                handoff.register_file(p, u8[ch], hdn, writer=write)
             success = True
         except Exception as e:
             self.print_clean(f"   Encoding failed: AF3 encoding failed: {e}")

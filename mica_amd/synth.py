@@ -90,7 +90,7 @@ def stress_case(kind: str, S: int):
 
 
 # The 64^3 single-tile cases that have a float64-truth fixture (tests/golden/truth64_S64_sub_<case>.npz, generator:
-# oracle/gen_golden_r5.py): case -> (weights seed, final gain, input seed) for uniform density + Bernoulli(1e-3) encodings.
+# gen_golden_r5.py in the test infrastructure): case -> (weights seed, final gain, input seed) for uniform density + Bernoulli(1e-3) encodings.
 # The first four reuse the inputs of model_S64_*_sub*.npz; s101..s104 are four more input seeds of the weight set whose golden
 # sits closest to the 1e-4 bar.
 CASES64 = {

@@ -2,7 +2,8 @@
 process, rendezvous on 127.0.0.1, every rank on cuda:0): runs VolumePredictor.predict_volume_sharded with the real engine;
 rank 0 writes the four volumes.  MICA_TEST_BACKEND=gloo (default; two ranks, records staged through the host) or nccl
 (= RCCL; ONE rank with force_collective, which executes the production branch of RecordExchange: device tensors,
-all_gather_into_tensor(async_op=True), work.wait() ordering, double-buffered slots)."""
+all_gather_into_tensor(async_op=True), work.wait() ordering, double-buffered slots).  MICA_TEST_MODE=root: the round-5 form - encodings
+resident as uint8, records gathered into rank 0 alone (dist.gather), volumes downloaded slab by slab behind the stitch."""
 import os
 import sys
 
@@ -39,7 +40,11 @@ def main():
     else:
         af[:, :, :, : shape[2] // 2] = 0                   # some tiles see no atoms: per-tile gating on every rank
     stats = {}
-    out = VolumePredictor(eng, grid, pad, batch).predict_volume_sharded(vol, af, force_collective=force, stats=stats)
+    root_mode = os.environ.get("MICA_TEST_MODE", "") == "root"
+    if root_mode:
+        af = af.to(torch.uint8)
+    out = VolumePredictor(eng, grid, pad, batch).predict_volume_sharded(vol, af, force_collective=force, stats=stats, to_host=root_mode,
+                                                                        gather_to_root=root_mode)
     # coverage of the sharded stitch: all-one records through the same exchange fill a counter volume (no hole), and
     # sharded_records itself raises unless every batch arrived exactly once
     from mica_amd.dist import sharded_records
@@ -47,10 +52,10 @@ def main():
     cover = torch.zeros((1, *shape), device="cuda")
     ones = torch.ones((batch, 1, grid, grid, grid), device="cuda")
     sharded_records(lambda first, count: ones[:count], lambda rec, first: eng.stitch_tiles(rec.contiguous(), cover, grid, 0, first),
-                    T, batch, (1, grid, grid, grid), torch.device("cuda"), stitch_rank=0, force_collective=force)
+                    T, batch, (1, grid, grid, grid), torch.device("cuda"), stitch_rank=0, force_collective=force, gather_to_root=root_mode)
     if dist.get_rank() == 0:
         np.savez(out_path, coverage=cover[0].cpu().numpy(), collectives=stats["collectives"], backend=str(stats["backend"]),
-                 **{k: v.cpu().numpy() for k, v in out.items()})
+                 collective=str(stats["collective"]), **{k: (v if root_mode else v.cpu().numpy()) for k, v in out.items()})
     else:
         assert out is None
     dist.barrier()

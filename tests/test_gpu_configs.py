@@ -77,6 +77,8 @@ def test_config0_chained_plumbing_mrc_pdb_to_volumes(tmp_path, eng, weights):
     res_map = gc.create_normalized_map_grids(normalized_map_path=dp.normalized_map_path, output_dir=os.path.join(grids, "normalized_map_grids"))
     res_af = gc.create_AF3_encodings_grids(AF3_encodings_path=str(inp / "AF3_encodings"), output_dir=os.path.join(grids, "AF3_encoding_grids"),
                                            parallel=True)
+    # the wrappers return when the volumes are resident and registered; the tile files come from a background writer
+    assert gc.wait_for_files() == 4 + 96
     norm_ref, _, _ = vo.normalise_map(raw)
     vol_ref, off = vo.transpose_axes(norm_ref, 1, 2, 3, [7, 6, 5])
     enc_ref = ao.rasterise_atoms(np.array(coords, np.float32), anames, ares, (2.0, -3.0, 1.5), raw.shape)
@@ -104,6 +106,34 @@ def test_config0_chained_plumbing_mrc_pdb_to_volumes(tmp_path, eng, weights):
     ok, vols = pred.run_prediction()
     assert ok and vols["amino_acid_probability"].shape == (20, 60, 50, 40)
     assert pred.sample_count == 4 and pred.use_optimized_batching is False
+    # the predictor took the volumes GridCreator left on the GPU (mica_amd/handoff.py) - the encodings as uint8 -, not the files
+    assert pred.resident is not None and pred.resident[1] is not None and pred.resident[1].volume.dtype == torch.uint8
+    # ... and the same class reading the FILES (what a predictor in another process does) returns the same volumes bit for bit
+    cold = CryoEMPredictor(model_path=ck, grids_path=grids + "/", output_path=str(tmp_path / "out"), save_output=False, device="cuda", quiet=True)
+    cold.use_resident_volumes = False
+    ok2, vols2 = cold.run_prediction()
+    assert ok2 and cold.resident is None
+    for k in vols:
+        assert np.array_equal(vols[k], vols2[k]), k
+    # ... and so does a predictor in a FRESH process, which has nothing but the files (the cold path)
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, sys.argv[1]);"
+            "from mica_amd.predict import CryoEMPredictor;"
+            "p = CryoEMPredictor(model_path=sys.argv[2], grids_path=sys.argv[3], output_path=sys.argv[4], save_output=False, device='cuda', quiet=True);"
+            "ok, v = p.run_prediction(); assert ok and p.resident is None; np.savez(sys.argv[5], **v)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code, root, ck, grids + "/", str(tmp_path / "out3"), str(tmp_path / "cold.npz")], check=True, timeout=600)
+    vols3 = np.load(str(tmp_path / "cold.npz"))
+    for k in vols:
+        assert np.array_equal(vols[k], vols3[k]), k
+    # deleting grids_path (utils/modeler.py:755 does after every map) invalidates the hand-off: nothing resident is found for it again
+    import shutil
+    from mica_amd import handoff
+    shutil.rmtree(grids)
+    assert handoff.lookup_grids(os.path.join(grids, "normalized_map_grids")) is None
+    gone = CryoEMPredictor(model_path=ck, grids_path=grids + "/", output_path=str(tmp_path / "out"), save_output=False, device="cuda", quiet=True)
+    assert gone.run_prediction() == (False, {})
     # the disk-free pipeline on the same normalised map + encodings
     vp = VolumePredictor(eng, 48, 8, batch=4)
     d_vol = torch.from_numpy(np.ascontiguousarray(vol_ref)).cuda()
@@ -191,10 +221,12 @@ def test_reference_batching_mode_vs_reference_golden(tmp_path, weights, golden_d
     assert np.abs(got["refbatch"]["backbone_probability"][:48] - got["single"]["backbone_probability"][:48]).max() > 1e-3
 
 
-def test_config2_two_ranks_on_one_gpu_equal_single_rank(tmp_path, eng):
+@pytest.mark.parametrize("mode", ["", "root"])
+def test_config2_two_ranks_on_one_gpu_equal_single_rank(tmp_path, eng, mode):
     """BASELINE configs[2] in miniature: two fresh rank processes (gloo rendezvous, both on cuda:0) run
     predict_volume_sharded with the real engine - round-robin batches, double-buffered record exchange, rank 0 stitches -
-    and must reproduce the single-process result bit for bit."""
+    and must reproduce the single-process result bit for bit.  mode "root" (round 5): encodings resident as uint8 on both ranks,
+    records gathered into rank 0 only, the volumes downloaded slab by slab behind the stitch."""
     from mica_amd.pipeline import VolumePredictor
     shape, batch = (100, 70, 50), 2                        # 3 x 2 x 2 = 12 tiles -> 6 batches -> 3 rounds per rank
     out = str(tmp_path / "sharded.npz")
@@ -202,12 +234,15 @@ def test_config2_two_ranks_on_one_gpu_equal_single_rank(tmp_path, eng):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   MICA_TEST_MODE=mode)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), out, "x".join(map(str, shape)), str(batch)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     got = np.load(out)
+    assert str(got["collective"]) == ("gather" if mode == "root" else "all_gather")
+    assert np.array_equal(got["coverage"], np.ones(shape, np.float32))
     vol = torch.from_numpy(synth_density(shape, 91)).cuda()
     af = torch.from_numpy(synth_af(shape, 91, 2e-3)).cuda()
     af[:, :, :, : shape[2] // 2] = 0
@@ -217,8 +252,10 @@ def test_config2_two_ranks_on_one_gpu_equal_single_rank(tmp_path, eng):
     assert float(ref["backbone_probability"].max()) > 0.5
 
 
-def test_config2_rccl_branch_single_rank_equals_plain_pipeline(tmp_path, eng):
-    """The production branch of the record exchange - RCCL all_gather_into_tensor(async_op=True) on device tensors, work.wait()
+@pytest.mark.parametrize("mode", ["", "root"])
+def test_config2_rccl_branch_single_rank_equals_plain_pipeline(tmp_path, eng, mode):
+    """(mode "root": the same with RCCL's gather into the stitching rank, uint8 encodings and the slab-by-slab download.)
+    The production branch of the record exchange - RCCL all_gather_into_tensor(async_op=True) on device tensors, work.wait()
     ordering against the stitch kernels, double-buffered send / receive slots - executed on the hardware that exists: ONE rank in
     an `nccl` process group with force_collective (a fresh child process that initialises the group before any other GPU call).
     predict_volume_sharded under it equals predict_volume bit for bit, every batch went through a collective, and an all-ones
@@ -229,12 +266,12 @@ def test_config2_rccl_branch_single_rank_equals_plain_pipeline(tmp_path, eng):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-               HSA_ENABLE_IPC_MODE_LEGACY="0", MICA_TEST_BACKEND="nccl")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MICA_TEST_BACKEND="nccl", MICA_TEST_MODE=mode)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), out, "x".join(map(str, shape)), str(batch)],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
     got = np.load(out)
-    assert str(got["backend"]) == "nccl" and int(got["collectives"]) == 6
+    assert str(got["backend"]) == "nccl" and int(got["collectives"]) == 6 and str(got["collective"]) == ("gather" if mode == "root" else "all_gather")
     assert np.array_equal(got["coverage"], np.ones(shape, np.float32))
     vol = torch.from_numpy(synth_density(shape, 91)).cuda()
     af = torch.from_numpy(synth_af(shape, 91, 2e-3)).cuda()

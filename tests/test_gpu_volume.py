@@ -252,6 +252,7 @@ def test_gridcreator_and_preprocessor_mirrors(tmp_path, eng):
     vol, off = vo.transpose_axes(ref, 1, 2, 3, [7, 6, 5])
     tiles, idx = vo.tile_volume(vol, 48, 8)
     assert res["success"] and res["grid_count"] == len(idx) == 4 and res["offset"] == off == [5.0, 6.0, 7.0]
+    assert gc.wait_for_files() == 4                                   # the tile files come from a background writer
     files = glob.glob(str(tmp_path / "grids" / "normalized_map_grids" / "*.npz"))
     assert len(files) == 4
     for t, (i, j, k, di, dj, dk) in enumerate(idx):
