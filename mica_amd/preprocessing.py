@@ -23,7 +23,14 @@ _MAP_TYPES = {np.dtype(np.float32): 0, np.dtype(np.int8): 1, np.dtype(np.int16):
 
 
 class DataPreprocessor:
-    def __init__(self, map_path, AF3_results, quiet=False, engine: Engine | None = None, device=0):
+    def __init__(self, map_path, AF3_results, quiet=False, engine: Engine | None = None, device=0, write_files: str = "sync"):
+        """write_files: "sync" (default) - the MRC files this stage is called for (the normalised map, the 24 encoding channels)
+        exist when its methods return, as at the reference's call sites (utils/modeler.py:675-683); "background" - they are written
+        behind the caller's back (joined by `mica_amd.mrc.read_mrc`, by the predictor mirror and at process exit): for a caller whose
+        next stage is the `GridCreator` mirror of this process, which takes the volumes from the GPU either way (mica_amd/handoff.py)."""
+        if write_files not in ("sync", "background"):
+            raise ValueError("write_files must be 'sync' or 'background'")
+        self.write_files = write_files
         self.map_path = map_path
         self.AF3_results = AF3_results
         self.quiet = quiet
@@ -82,6 +89,8 @@ class DataPreprocessor:
             if os.path.exists(path):
                 os.remove(path)
             handoff.register_file(path, t, hdn, writer=write)
+            if self.write_files == "sync":
+                handoff.wait_file(path)
             success = True
         except Exception as e:
             self.logger.error(f"Map processing failed: {e}")
@@ -129,6 +138,9 @@ class DataPreprocessor:
                     mrc.write_mrc(p, u8[ch].cpu().numpy().astype(np.float32), voxel_size=(1.0, 1.0, 1.0), origin=hd.origin, mapc=hd.mapc,
                                   mapr=hd.mapr, maps=hd.maps, nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart)
                 handoff.register_file(p, u8[ch], hdn, writer=write)
+            if self.write_files == "sync":                    # the 24 writers run on the file pool's threads; all joined here
+                for name in af3_encoding.CHANNEL_NAMES:
+                    handoff.wait_file(os.path.join(self.AF3_encodings, f"{name}_encoding.mrc"))
             success = True
         except Exception as e:
             self.print_clean(f"   Encoding failed: AF3 encoding failed: {e}")

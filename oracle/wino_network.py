@@ -25,6 +25,9 @@ Variants of the 3^3 convs:
     f43s, f43s@e2   the same with the points {0, +-3/2, +-2/3, inf} of the shipped kernel (kernels_conv43.hip)
     f43s@e2t1, f43s@e2t   encoder.2 plus the transition conv of encoder.1 / of encoder.0 and encoder.1 (the other Cout % 128 == 0 layers
                     whose operand comes straight out of a 1x1 conv's epilogue)
+    f43s@late, @latefpn, @lateheads, @latec1, @latec2   (round 5) encoder.2 plus the LATE narrow layers - the FPN's three smooth convs
+                    (64 -> 64) and / or the heads' conv1 (192 / 196 / 200 -> 64) and conv2 (64 -> 32): the layers the bn = 64 / 32
+                    variants of the F(2,3) kernel spend 0.47 / 0.29 of the MFMA peak on
 
 Criterion (tests/test_gpu_model.py): scaled error max |got - ref| / max(|ref|, rms(ref)) < 1e-4 against the reference module's
 float32 logits (tests/golden/model_S16_*.npz) AND against its float64 logits (truth64_S16_*.npz), the latter also <= 1.5x the
@@ -196,6 +199,12 @@ class Emulated:
 
     def pick(self, cin, cout, name=""):
         v = self.variant
+        if "@late" in v:                                  # encoder.2 plus subsets of the late narrow layers behind it (round 5)
+            sets = {"@late": ("fpn.smooth.", "backbone_head.conv", "ca_head.conv", "aa_head.conv"), "@latefpn": ("fpn.smooth.",),
+                    "@lateheads": ("backbone_head.conv", "ca_head.conv", "aa_head.conv"),
+                    "@latec1": ("backbone_head.conv1", "ca_head.conv1", "aa_head.conv1"),
+                    "@latec2": ("backbone_head.conv2", "ca_head.conv2", "aa_head.conv2")}
+            return F43S if name.startswith(("encoder.2.",) + sets["@" + v.split("@")[1]]) else F23
         if "@e2t" in v:                                   # encoder.2 and the transition of encoder.1 (@e2t1) or of encoder.0 and encoder.1 (@e2t)
             extra = ("encoder.1.transition",) if "@e2t1" in v else ("encoder.0.transition", "encoder.1.transition")
             return {"f43": F43, "f43h": F43H, "f43s": F43S}[v.split("@")[0]] if name.startswith(("encoder.2.",) + extra) else F23

@@ -68,7 +68,9 @@ def test_config0_chained_plumbing_mrc_pdb_to_volumes(tmp_path, eng, weights):
     pdb.write_text("".join(lines) + "END\n")
 
     # --- getData ------------------------------------------------------------------------------------------------------
-    dp = DataPreprocessor(map_path=map_path, AF3_results=str(inp / "AF3_results"), quiet=True, engine=eng)
+    # write_files="background": the normalised map and the 24 encoding MRCs are written behind the call, the volumes go to GridCreator
+    # through the registry of mica_amd/handoff.py (the default, "sync", is exercised by every other DataPreprocessor test)
+    dp = DataPreprocessor(map_path=map_path, AF3_results=str(inp / "AF3_results"), quiet=True, engine=eng, write_files="background")
     dp.resample_and_normalize_map()
     assert dp.normalized_map_path == str(inp / "resampled_normalized_map.mrc")
     assert dp.create_AF3_encodings(str(pdb)) is True
