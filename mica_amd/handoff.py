@@ -247,8 +247,14 @@ def _at_exit():
             _unmark(e)
 
 
-import atexit  # noqa: E402
-atexit.register(_at_exit)
+# At interpreter exit the files a caller asked for must be complete.  An ordinary atexit handler runs too late: threading's own
+# shutdown (which stops concurrent.futures' pools - the writers could no longer submit - and joins non-daemon threads) comes first;
+# threading._register_atexit callbacks run at the start of that shutdown, last registered first, i.e. before the pools are stopped.
+try:
+    threading._register_atexit(_at_exit)
+except Exception:                                # an interpreter without that hook
+    import atexit
+    atexit.register(_at_exit)
 
 
 # ---- the reference's tile files, written off the critical path -----------------------------------------------------------------------
@@ -333,7 +339,7 @@ class TileFileWriter:
     one of two pinned buffers and hands one job per file to the pool; `wait()` joins, `cancel()` drops what has not been started."""
 
     def __init__(self, engine, volume: torch.Tensor, table: np.ndarray, targets, grid_size: int, padding: int, constant_members: dict,
-                 file_dtype=np.float32, min_grid_max=None, threads: int | None = None, chunk_bytes: int = 192 << 20):
+                 file_dtype=np.float32, min_grid_max=None, chunk_bytes: int = 64 << 20):
         """volume: f32 / u8 [C,N0,N1,N2] on the engine's device; targets: [(directory, file prefix)] per channel."""
         self.engine, self.volume, self.table, self.targets = engine, volume, table, list(targets)
         self.grid, self.pad, self.W = grid_size, padding, grid_size + 2 * padding
@@ -343,7 +349,6 @@ class TileFileWriter:
         C = volume.shape[0]
         assert C == len(self.targets)
         self.chunk = max(1, min(len(table), chunk_bytes // (C * self.W ** 3 * 4)))
-        self.threads = threads or max(2, min(12, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8) - 2))
         self.written = 0
         self.skipped = 0
         self.error: Exception | None = None
@@ -408,10 +413,11 @@ class TileFileWriter:
             torch.cuda.set_device(e.device)
             stream = torch.cuda.Stream(device=e.device)
             C, W, T = self.volume.shape[0], self.W, len(self.table)
-            pins = [torch.empty((self.chunk, C, W, W, W), dtype=torch.float32).pin_memory() for _ in range(2)]
+            pins = [_take_pinned(self.chunk * C * W ** 3).view(self.chunk, C, W, W, W) for _ in range(2)]
             devs = [torch.empty((self.chunk, C, W, W, W), dtype=torch.float32, device=e.device) for _ in range(2)]
             inflight = [[], []]
-            with ThreadPoolExecutor(max_workers=self.threads, thread_name_prefix="mica-npz") as pool:
+            pool = _npz_pool()
+            try:
                 for n, first in enumerate(range(0, T, self.chunk)):
                     if self._cancel.is_set():
                         break
@@ -429,6 +435,45 @@ class TileFileWriter:
                 for fs in inflight:
                     for f in fs:
                         f.result()
+            finally:
+                for fs in inflight:                  # after an error: nothing may still read the staging buffers when they go back
+                    for f in fs:
+                        f.exception()
+                for pbuf in pins:
+                    _give_pinned(pbuf)
         except Exception as ex:
             self.error = ex
             self._cancel.set()
+
+
+# One pool of writer threads and a small cache of pinned staging buffers for every TileFileWriter of the process: two writers (map and
+# encodings) run at the same time behind every getData, and neither a thread pool per writer nor page-locking fresh staging memory
+# per map is free for the caller they run beside (hipHostMalloc serialises with the caller's own uploads).
+_NPZ_POOL = None
+_PINNED: list = []
+
+
+def _npz_pool():
+    global _NPZ_POOL
+    with _LOCK:
+        if _NPZ_POOL is None:
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+            _NPZ_POOL = ThreadPoolExecutor(max_workers=max(2, min(8, cores - 4)), thread_name_prefix="mica-npz")
+        return _NPZ_POOL
+
+
+def _take_pinned(n_floats: int) -> torch.Tensor:
+    with _LOCK:
+        for i, t in enumerate(_PINNED):
+            if t.numel() >= n_floats:
+                return _PINNED.pop(i)[:n_floats]
+    return torch.empty((n_floats,), dtype=torch.float32).pin_memory()
+
+
+def _give_pinned(t: torch.Tensor):
+    base = t._base if t._base is not None else t
+    while base._base is not None:
+        base = base._base
+    with _LOCK:
+        if len(_PINNED) < 4:
+            _PINNED.append(base.view(-1))

@@ -25,45 +25,88 @@ class SlabDownloader:
     """Brings the stitched volumes to the host WHILE the map is still being computed.
 
     Tiles are processed in the reference's order (utils/create_grids.py:143-145: x outermost), so once the tiles of an x block
-    have been stitched the slab out[:, i:i+grid] is final: its 23 channel pieces (each contiguous) are copied into a pinned host
-    buffer on a copy stream behind an event of the stitching stream.  What is left when the last tile is done is the last slab
-    only - at 512^3, 1.1 of 12.3 GB.  The pinned buffer is allocated on a helper thread (page-locking 12 GB takes longer than the
-    first slab needs to compute)."""
+    have been stitched the slab out[:, i:i+grid] is final.  It is copied into one of two pinned staging buffers on a copy stream,
+    behind an event of the stitching stream, and a helper thread unpacks the staging buffer into the result array (ordinary
+    pageable memory: page-locking a whole 12.3-GB result costs more than the first slab takes to compute, and the first download
+    would wait for it) while the GPU works on the next slabs.  What is left when the last tile is done is the last slab only - at
+    512^3, 1.1 of 12.3 GB."""
 
     def __init__(self, out: torch.Tensor, grid: int, tiles_per_slab: int):
+        import queue
         import threading
+
+        import numpy as np
         self.out, self.grid, self.per = out, grid, tiles_per_slab
-        self.n0 = out.shape[1]
+        self.C, self.n0 = out.shape[0], out.shape[1]
         self.nslabs = -(-self.n0 // grid)
         self.stream = torch.cuda.Stream(device=out.device)
         self.next = 0
-        self.host = None
+        self.host = np.empty(tuple(out.shape), dtype=np.float32)        # the result: views of it are what the caller gets
+        self.stage = [None, None]
+        self.free = [threading.Event(), threading.Event()]               # staging buffer k has been unpacked
+        self.jobs = queue.Queue()
+        self.error = None
 
         def alloc():
-            self.host = torch.empty(out.shape, dtype=out.dtype).pin_memory()
+            for k in range(2):
+                self.stage[k] = torch.empty((self.C, min(grid, self.n0), *out.shape[2:]), dtype=out.dtype).pin_memory()
+                self.free[k].set()
+
+        def unpack():
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=4, thread_name_prefix="mica-slab-copy") as pool:      # numpy's copy releases the GIL
+                def piece(k, lo, hi, c0, c1):
+                    self.host[c0:c1, lo:hi] = self.stage[k][c0:c1, :hi - lo].numpy()
+                while True:
+                    job = self.jobs.get()
+                    if job is None:
+                        return
+                    k, lo, hi, ev = job
+                    try:
+                        ev.synchronize()
+                        step = -(-self.C // 4)
+                        for f in [pool.submit(piece, k, lo, hi, c0, min(c0 + step, self.C)) for c0 in range(0, self.C, step)]:
+                            f.result()
+                    except Exception as ex:      # reported by finish()
+                        self.error = ex
+                    finally:
+                        self.free[k].set()
         self._alloc = threading.Thread(target=alloc, name="mica-pinned-alloc")
         self._alloc.start()
+        self._unpack = threading.Thread(target=unpack, name="mica-slab-unpack")
+        self._unpack.start()
+
+    def _download(self, s: int):
+        k = s & 1
+        if self.stage[k] is None:
+            self._alloc.join()
+        self.free[k].wait()                      # slab s - 2 has left this staging buffer (long ago: a slab computes for far longer)
+        self.free[k].clear()
+        lo, hi = s * self.grid, min((s + 1) * self.grid, self.n0)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.out.device))
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            for c in range(self.C):              # each channel's slab is one contiguous run of the volume
+                self.stage[k][c, :hi - lo].copy_(self.out[c, lo:hi], non_blocking=True)
+            done.record(self.stream)
+        self.jobs.put((k, lo, hi, done))
 
     def tiles_done(self, n_tiles: int):
         """`n_tiles` tiles (in table order) have been stitched on the current stream: download every slab they complete."""
         complete = min(n_tiles // self.per, self.nslabs)
-        if complete <= self.next:
-            return
-        if self.host is None:
-            self._alloc.join()
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.out.device))
-        lo, hi = self.next * self.grid, min(complete * self.grid, self.n0)
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_event(ev)
-            for c in range(self.out.shape[0]):
-                self.host[c, lo:hi].copy_(self.out[c, lo:hi], non_blocking=True)
-        self.next = complete
+        while self.next < complete:
+            self._download(self.next)
+            self.next += 1
 
-    def finish(self) -> torch.Tensor:
-        """-> the pinned host tensor [23, N0, N1, N2], complete."""
+    def finish(self):
+        """-> the host array [23, N0, N1, N2] (numpy), complete."""
         self.tiles_done(self.per * self.nslabs)
-        self.stream.synchronize()
+        self.jobs.put(None)
+        self._unpack.join()
+        if self.error is not None:
+            raise self.error
         return self.host
 
 
@@ -107,7 +150,7 @@ class VolumePredictor:
             if dl is not None:
                 dl.tiles_done(first + count)
         if dl is not None:
-            return volume_dict(dl.finish().numpy())
+            return volume_dict(dl.finish())
         return volume_dict(out)
 
     def predict_maps_streamed(self, maps, afs=None):
@@ -232,5 +275,5 @@ class VolumePredictor:
         if rank != 0:
             return None
         if dl is not None:
-            return volume_dict(dl.finish().numpy())
+            return volume_dict(dl.finish())
         return volume_dict(out)

@@ -230,7 +230,7 @@ class CryoEMPredictor:
                     x.record_stream(main_stream)
                     if af is not None:
                         af.record_stream(main_stream)
-            vols = volume_dict(dl.finish().numpy())
+            vols = volume_dict(dl.finish())
             self.timing_stats['inference'] = time.time() - t0
             return vols
         except Exception as e:
