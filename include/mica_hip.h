@@ -84,8 +84,10 @@ int mica_finalize_weights(mica_ctx* ctx);
 /* Which dense 3x3x3 convs run on the Winograd F(4,3)-along-x kernel (1.33x fewer MFMAs, ~4x the per-layer rounding error) instead
  * of F(2,3): 0 = none; 1 = the four convs of encoder.2 (models/model.py:107,115,122,142 at C = 256: 68 % of the network's FLOPs) -
  * the default: whole-network error indistinguishable from mode 0 (profiles/r04_wino_network_numerics.txt); 2 = those and encoder.1's
- * transition conv (128 -> 256, 6 % of the FLOPs: +0.7 % throughput, rms error +1-2 %, profiles/r04_f43_ab_bench.txt).  Also settable
- * through the environment (MICA_F43=0|1|2, read by mica_create).  The variant decides how weights are packed: before
+ * transition conv (128 -> 256, 6 % of the FLOPs: +0.7 % throughput, rms error +1-2 %, profiles/r04_f43_ab_bench.txt); 3 = mode 1 and
+ * the late narrow layers - the FPN's three smooth convs (64 -> 64) and the heads' conv1 (192 / 196 / 200 -> 64, models/model.py:165-174,
+ * 210) - on the kernel's 64-channel variant (the two wave groups split the taps; profiles/r05_wino_late_numerics.txt).  Also settable
+ * through the environment (MICA_F43=0|1|2|3, read by mica_create).  The variant decides how weights are packed: before
  * mica_finalize_weights.                                                                                                            */
 int mica_set_conv_variant(mica_ctx* ctx, int mode);
 int mica_get_conv_variant(const mica_ctx* ctx);
@@ -241,7 +243,7 @@ int mica_neighbour_matrix_np(mica_ctx* ctx, const double* d_cands, int64_t n, co
 int mica_op_conv3d(mica_ctx* ctx, const float* d_x, int batch, int cin, int d, int h, int w,
                    const float* h_w, const float* h_b, int cout, int k, float* d_y, void* stream);
 /* The same with the kernel named: variant 0 = Winograd F(2,3) along x (every layer's default), 1 = F(4,3) along x (k = 3 and
- * cout a multiple of 128: the kernel encoder.2's convs run on).                                                          */
+ * cout a multiple of 128 - the kernel encoder.2's convs run on - or cout = 64: its tap-split variant).                                                          */
 int mica_op_conv3d_variant(mica_ctx* ctx, const float* d_x, int batch, int cin, int d, int h, int w,
                            const float* h_w, const float* h_b, int cout, int k, int variant, float* d_y, void* stream);
 /* conv3x3x3(conv1x1x1(relu(InstanceNorm3d(x)))), NCDHW in and out: the fused form the forward graph uses for

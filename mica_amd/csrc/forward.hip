@@ -101,7 +101,8 @@ struct mica_ctx {
     int* cur_err = nullptr;          // ... of the run of tiles forward_run is working on
     float ascale = ASCALE_DEFAULT;   // activation scale of the split encoding (common.h) every forward call starts from
     int f43_mode = 1;                // 0: every 3^3 conv on the F(2,3) kernel; 1 (default): encoder.2's four convs on the F(4,3) kernel; 2: those and
-                                     // encoder.1's transition
+                                     // encoder.1's transition; 3: mode 1 and the late narrow layers (FPN smooth x3, the heads' conv1 x3) on its
+                                     // 64-channel variant
     float last_scale = ASCALE_DEFAULT;   // the lowest scale a tile of the last forward call needed (forward_checked)
     int last_retries = 0;                // tiles of the last forward call that had to be repeated at a lower scale
     std::vector<char> use_af;        // per tile of the last forward_impl call: AF3 branch taken
@@ -438,9 +439,11 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         if (e < 2) make_operand(c, c->R_a, B, 2 * C, c->v_mean, c->v_rstd, 1, view(c->S_c[e], 2 * cc, 0, 2 * cc), none, nullptr, st, f43_next);
         // FPN level e right away (model.py:182-205; the interpolations are identities): the lateral 1x1 reads c_e raw with the
         // transition's InstanceNorm + ReLU applied on load, and writes the smoothing conv's operand
-        run_conv1x1(c, c->lateral[e], raw_src(c->R_a, 2 * C, c->v_mean, c->v_rstd, 1), nullptr, view(c->S_l, 4, 0, 4), c->R_c, B, st);
+        // (conv variant 3: the smooth conv and the heads' conv1 run on the F(4,3) kernel's 64-channel variant; their operands - S_l, the
+        // FPN output, the earlier heads' logits - are written in that kernel's layout by their producers)
+        run_conv1x1(c, c->lateral[e], raw_src(c->R_a, 2 * C, c->v_mean, c->v_rstd, 1), nullptr, view(c->S_l, 4, 0, 4), c->R_c, B, st, c->smooth[e].f43);
         run_conv(c, c->smooth[e], SrcList().add(c->S_l, 4, 0, 4), c->R_b, B, st);
-        make_operand(c, c->R_b, B, 64, nullptr, nullptr, 0, view(c->S_fpn, 12, 4 * e, 4), none, nullptr, st);
+        make_operand(c, c->R_b, B, 64, nullptr, nullptr, 0, view(c->S_fpn, 12, 4 * e, 4), none, nullptr, st, c->heads[0].conv1.f43);
         X = c->S_c[e];
     }
     // ---- heads (model.py:230-239, 344-346) ------------------------------------------------------
@@ -459,7 +462,9 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         const bool feeds = h < 2;
         launch_head_final(c->R_b, B, V, c->v_mean, c->v_rstd, c->v_gate, H.wf, H.bf, H.ncls, outs[h], 4 * h,
                           feeds ? c->extra_raw : nullptr, 8, st);
-        if (feeds) launch_prep_ncdhw_wino(c->extra_raw, B, d, 8, view(c->S_extra, 1, 0, 1), SplitEnc{c->cur_err, c->ascale}, st);
+        if (feeds && c->heads[0].conv1.f43)
+            launch_prep_ncdhw_wino43(c->extra_raw, B, d, 8, view(c->S_extra, 1, 0, 1), SplitEnc{c->cur_err, c->ascale / WINO43_ASCALE_DIV}, st);
+        else if (feeds) launch_prep_ncdhw_wino(c->extra_raw, B, d, 8, view(c->S_extra, 1, 0, 1), SplitEnc{c->cur_err, c->ascale}, st);
     }
     return MICA_OK;
 }
@@ -628,7 +633,7 @@ int mica_create_dims(int device, int max_batch, int td, int th, int tw, mica_ctx
     }
     mica_ctx* c = new mica_ctx();
     if (const char* ev = getenv("MICA_STEM_MFMA")) c->stem_mode = atoi(ev) != 0;
-    if (const char* ev = getenv("MICA_F43")) { const int m = atoi(ev); c->f43_mode = m < 0 || m > 2 ? 1 : m; }      // A/B switch (0: the F(2,3) kernel everywhere)
+    if (const char* ev = getenv("MICA_F43")) { const int m = atoi(ev); c->f43_mode = m < 0 || m > 3 ? 1 : m; }      // A/B switch (0: the F(2,3) kernel everywhere)
     c->device = device;
     c->maxB = max_batch;
     c->S = tile_size;
@@ -698,7 +703,7 @@ int mica_load_weight(mica_ctx* c, const char* name, const float* h_data, const i
 
 int mica_set_conv_variant(mica_ctx* c, int mode) {
     if (!c) return MICA_ERR_ARG;
-    if (mode < 0 || mode > 2) { c->err = "mica_set_conv_variant: mode must be 0, 1 or 2"; return MICA_ERR_ARG; }
+    if (mode < 0 || mode > 3) { c->err = "mica_set_conv_variant: mode must be 0, 1, 2 or 3"; return MICA_ERR_ARG; }
     if (c->finalized) { c->err = "mica_set_conv_variant: weights already finalized (the variant decides how they are packed)"; return MICA_ERR_STATE; }
     c->f43_mode = mode;
     return MICA_OK;
@@ -791,7 +796,7 @@ int mica_finalize_weights(mica_ctx* c) {
         for (int i = 0; i < 3; ++i) { ex[i] = std::exp(fw->data[i] - m); s += ex[i]; }
         for (int i = 0; i < 3; ++i) {
             if ((r = setup_conv(c, c->lateral[i], "fpn.lateral." + std::to_string(i), 64, 1, {128 << i}, false))) return r;
-            if ((r = setup_conv(c, c->smooth[i], "fpn.smooth." + std::to_string(i) + ".0", 64, 3, {64}, false, ex[i] / s))) return r;
+            if ((r = setup_conv(c, c->smooth[i], "fpn.smooth." + std::to_string(i) + ".0", 64, 3, {64}, false, ex[i] / s, c->f43_mode == 3))) return r;
         }
     }
     const char* hn[3] = {"backbone_head", "ca_head", "aa_head"};
@@ -802,7 +807,8 @@ int mica_finalize_weights(mica_ctx* c) {
         const std::string p = std::string(hn[h]) + ".";
         std::vector<int> seg = {192};
         if (h > 0) seg.push_back(4 * h);
-        if ((r = setup_conv(c, H.conv1, p + "conv1", 64, 3, seg, false))) return r;
+        // (mode 3) the three conv1 read the same operands (the FPN output, the earlier heads' logits): they switch together
+        if ((r = setup_conv(c, H.conv1, p + "conv1", 64, 3, seg, false, 1.f, c->f43_mode == 3))) return r;
         if ((r = setup_conv(c, H.conv2, p + "conv2", 32, 3, {64}, false))) return r;
         if ((r = setup_gate(c, H.cal, p + "calibration.1", p + "calibration.4", 32, 8, false))) return r;
         const HostTensor *wf = find(c, p + "final.weight"), *bf = find(c, p + "final.bias");
@@ -1094,8 +1100,8 @@ int mica_op_conv3d_variant(mica_ctx* c, const float* d_x, int batch, int cin, in
                            int cout, int k, int variant, float* d_y, void* stream) {
     if (!c) return MICA_ERR_ARG;
     if (!d_x || !h_w || !h_b || !d_y || batch < 1 || cin < 1 || cin > 1024 || cout < 32 || cout > 1024 || cout % 32 || (k != 1 && k != 3) || !op_box_ok(batch, d, h, w) ||
-        (k == 1 && cout != 64 && cout != 128 && cout != 256) || variant < 0 || variant > 1 || (variant == 1 && (k != 3 || cout % 128))) {
-        c->err = "mica_op_conv3d: bad argument (k = 3: cout a multiple of 32, of 128 for the F(4,3) variant; k = 1: cout in {64, 128, 256}; cin <= 1024)" OP_BOX_MSG;
+        (k == 1 && cout != 64 && cout != 128 && cout != 256) || variant < 0 || variant > 1 || (variant == 1 && (k != 3 || (cout % 128 && cout != 64)))) {
+        c->err = "mica_op_conv3d: bad argument (k = 3: cout a multiple of 32 - of 128, or 64, for the F(4,3) variant; k = 1: cout in {64, 128, 256}; cin <= 1024)" OP_BOX_MSG;
         return MICA_ERR_ARG;
     }
     const bool f43 = variant == 1;
@@ -1155,7 +1161,7 @@ int mica_op_norm_conv1_conv3_variant(mica_ctx* c, const float* d_x, int batch, i
     if (!c) return MICA_ERR_ARG;
     const bool f43 = variant == 1;
     if (!d_x || !h_w1 || !h_b1 || !h_w3 || !h_b3 || !d_y || batch < 1 || cin < 16 || !pow2_8_512(cin) || (cmid != 64 && cmid != 128 && cmid != 256) ||
-        cout < 32 || cout > 1024 || cout % 32 || !op_box_ok(batch, d, h, w) || variant < 0 || variant > 1 || (f43 && cout % 128)) {
+        cout < 32 || cout > 1024 || cout % 32 || !op_box_ok(batch, d, h, w) || variant < 0 || variant > 1 || (f43 && cout % 128 && cout != 64)) {
         c->err = "mica_op_norm_conv1_conv3: bad argument (cin a power of two in [16,512], cmid in {64,128,256}, cout a multiple of 32, <= 1024)" OP_BOX_MSG;
         return MICA_ERR_ARG;
     }

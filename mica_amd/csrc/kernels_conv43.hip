@@ -31,6 +31,14 @@
 // = 64 accumulator VGPRs, three waves per SIMD.  LDS image per chunk: 4 planes (hi/lo x k-half) x [z 6][p 6][y 4][quad 8] 16-B
 // slots = 73,728 B, double buffered.  Per chunk and workgroup 2,688 MFMAs instead of 3,584 for the same 256 voxels x 128
 // channels; a weight fragment feeds 4 MFMAs (8 in the F(2,3) kernel: the weight stream from L2 is 1.5x per output).
+//
+// BN = 64 (round 5: the FPN's smooth convs 64 -> 64 and the heads' conv1 192 / 196 / 200 -> 64, reference models/model.py:165-174,210):
+// as conv_wino16_kernel<64>, the two wave groups own the SAME 64 channels and SPLIT THE TAPS - group 0 taps 0..3 and the hi x hi /
+// lo x hi products of tap 8 ("x"), group 1 taps 4..7 and tap 8's hi x lo product ("y") - seven steps per chunk each instead of
+// fourteen; per-wave tile, operand reuse and weight bytes per MFMA stay those of the 128 variant.  One instruction stream serves
+// both groups (tap offsets and weight offsets are per-group scalars); the partial sums meet in the epilogue: group 0 stores its
+// accumulators into the transform tile, group 1 adds its own (ds_add_f32, one add per address: deterministic).  Oracle:
+// oracle/wino_network.py f43s@late (profiles/r05_wino_late_numerics.txt): the rms distance from the float64 truth moves by < 1.5 %.
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -112,12 +120,16 @@ __device__ __forceinline__ const _Float16* chunk_base_wino43(const ConvSrcs& s, 
 // the MFMA arbiter serving the three waves of a SIMD oldest first (waves 0-3 finish a chunk after ~8 K cycles and idle ~5 K at its
 // barrier, waves 8-11 are the critical path at 13 K) and a DMA costing its wave ~170 cycles, but with the old waves issuing all of them
 // the chunk took as long: the request path they occupy is the one the young waves' weight loads wait on.
+template <int BN_>
 __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
                                                           const float* __restrict__ bias, float out_scale, float* __restrict__ out,
                                                           Dims d, int cout, int total_chunks, int ntx, int nty, int nnb,
                                                           int items_per_b, int total_items, float* __restrict__ stats_ws) {
     using G = Geo43;
-    constexpr int BN = G::BN, NCT = 4, NS = 14, NF = 4;      // NS: steps per chunk (4 x (a, b, c) + x + y)
+    constexpr int BN = BN_, NCT = 4, NF = 4;
+    constexpr bool SPLIT = BN == 64;                         // the two wave groups split the taps instead of the channels
+    constexpr int NS = SPLIT ? 7 : 14;                       // steps per wave and chunk: 4 x (a, b, c) + x + y, or 2 x (a, b, c) + x|y
+    static_assert(BN == 128 || BN == 64, "channel block");
     constexpr int DW = G::NW, DPW = G::NDMA / DW, DPS = DPW / 6;      // waves that issue slab DMAs, DMAs per wave and chunk, per step
     static_assert(G::NDMA % DW == 0 && DPW % 6 == 0 && DPS == 1, "slab DMA plan: one per wave and step in the first six steps");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -146,7 +158,12 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     constexpr int chstride = 5 * psstride;                  // 491,520
     const unsigned w_common = (unsigned)((lg & 1) * BN + lr) * 16u;
     const int64_t nbstride = (int64_t)total_chunks * chstride;
-    const char* wwave = reinterpret_cast<const char*>(wpk) + wp * 8 * ustride + wn * 64 * 16;
+    const char* wwave = reinterpret_cast<const char*>(wpk) + wp * 8 * ustride + (SPLIT ? 0 : wn * 64 * 16);
+    // SPLIT: group wn works on pair-steps 2 wn ("A") and 2 wn + 1 ("B") and on its half of tap 8; wave-uniform scalars
+    const int sp_at[2] = {wn ? (G::PZ + G::QX) * 16 : 0, wn ? 2 * G::PZ * 16 : 2 * G::QX * 16};          // W43_AOFF_TAP(4 wn), (4 wn + 2)
+    const int sp_pd[2] = {G::QX * 16, wn ? G::QX * 16 : (G::PZ - 2 * G::QX) * 16};                         // W43_PAIRDELTA(2 wn), (2 wn + 1)
+    const int sp_wo[3] = {2 * wn * psstride, (2 * wn + 1) * psstride, 4 * psstride + (wn ? 4 * ustride : 0)};  // weights of A, B, tap 8 (H | L)
+    const int sp_d4 = wn ? 2 * BN * 16 : 0;                                                                // tap 8: y reads [b_lo ; 0], x [b_hi ; b_hi]
 
     // Weight fragments and the step schedule.  The three split products of a tap pair (t, t') are grouped so that operands are
     // shared between MFMAs:  with  Ahi = [a_hi(t) | a_hi(t')], Alo = [a_lo(t) | a_lo(t')]  (k-groups 0,1 = the two channel halves at
@@ -160,8 +177,13 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     // pair-steps of a chunk the assignment is back where it started, so every index is a compile-time constant.  Both are
     // requested at the start of step a: L of this pair-step (used two steps later, in c) and H of the NEXT pair-step (three steps).
     half8 bq[3][NCT];
-#define W43_PS(st) ((st) < 12 ? (st) / 3 : 4)
-#define W43_KIND(st) ((st) < 12 ? (st) % 3 : (st) - 9)         /* 0 a, 1 b, 2 c, 3 x, 4 y */
+    // BN = 64 (SPLIT): steps a, b, c of the group's pair-steps A and B, then its tap-8 step z (kind 5: a single step).  Five fragment
+    // sets per chunk live in the same three register sets: LA, LB -> 0; HB, W4 (tap 8) -> 1; HA -> 2.  LA is requested in step 0 (used
+    // in 2), HB in 1 (used in 3, 4), LB in 3 (used in 5), the NEXT chunk's HA in 4 (HA is done after step 1) and W4 in 5 (HB is done
+    // after step 4; used in 6 - one step of lead, like the next chunk's first H in the 128 variant).
+#define W43_PS(st) (SPLIT ? ((st) < 6 ? (st) / 3 : 4) : ((st) < 12 ? (st) / 3 : 4))     /* SPLIT: slot 0 = A, 1 = B */
+#define W43_KIND(st) (SPLIT ? ((st) < 6 ? (st) % 3 : 5) : ((st) < 12 ? (st) % 3 : (st) - 9))         /* 0 a, 1 b, 2 c, 3 x, 4 y, 5 z */
+#define W43_SPSET(st) ((st) < 2 ? 2 : (st) == 2 || (st) == 5 ? 0 : 1)
 #define W43_HSET(ps) ((ps) == 4 ? 2 : (ps) & 1)
 #define W43_LSET(ps) ((ps) < 3 ? 2 : (ps) == 3 ? 0 : 1)
 #define W43_AOFF_TAP(tap) ((((tap) / 3) * G::PZ + ((tap) % 3) * G::QX) * 16)
@@ -181,12 +203,18 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     } while (0)
 #define MICA_BLOAD43_H(ps, base) MICA_BLOAD43(W43_HSET(ps), base, (ps) * psstride, (ps) == 4 ? 0 : 2 * BN * 16)
 #define MICA_BLOAD43_L(ps, base) MICA_BLOAD43(W43_LSET(ps), base, (ps) * psstride + 4 * ustride, 2 * BN * 16)
+    // SPLIT: the group's fragments; offsets are wave-uniform scalars (sp_wo), destinations fixed sets
+#define MICA_BLOAD43_SP_HA(base) MICA_BLOAD43(2, base, sp_wo[0], 2 * BN * 16)
+#define MICA_BLOAD43_SP_LA(base) MICA_BLOAD43(0, base, sp_wo[0] + 4 * ustride, 2 * BN * 16)
+#define MICA_BLOAD43_SP_HB(base) MICA_BLOAD43(1, base, sp_wo[1], 2 * BN * 16)
+#define MICA_BLOAD43_SP_LB(base) MICA_BLOAD43(0, base, sp_wo[1] + 4 * ustride, 2 * BN * 16)
+#define MICA_BLOAD43_SP_W4(base) MICA_BLOAD43(1, base, sp_wo[2], sp_d4)
 #define W43_WAIT(N, set) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bq[set][0]), "+v"(bq[set][1]), "+v"(bq[set][2]), "+v"(bq[set][3]))
     // wait until at most n (a compile-time constant after unrolling, 4 .. 14) vector-memory operations are outstanding
 #define W43_WAITN(n, set)                                                                                               \
     do {                                                                                                                \
-        static_assert((n) >= 4 && (n) <= 14, "wait immediates");                                                        \
-        if ((n) == 4) W43_WAIT(4, set); else if ((n) == 5) W43_WAIT(5, set); else if ((n) == 6) W43_WAIT(6, set);       \
+        static_assert((n) >= 1 && (n) <= 14, "wait immediates");                                                        \
+        if ((n) == 1) W43_WAIT(1, set); else if ((n) == 4) W43_WAIT(4, set); else if ((n) == 5) W43_WAIT(5, set); else if ((n) == 6) W43_WAIT(6, set);       \
         else if ((n) == 7) W43_WAIT(7, set); else if ((n) == 8) W43_WAIT(8, set); else if ((n) == 9) W43_WAIT(9, set);  \
         else if ((n) == 10) W43_WAIT(10, set); else if ((n) == 11) W43_WAIT(11, set); else if ((n) == 12) W43_WAIT(12, set); \
         else if ((n) == 13) W43_WAIT(13, set); else W43_WAIT(14, set);                                                  \
@@ -259,7 +287,7 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     Item nxt = decode(nitem < it_end ? nitem : item);
 
     // prologue of the first item: slab chunk 0 -> buffer 0, H fragments of the first pair-step
-    MICA_BLOAD43_H(0, cur.w);
+    if constexpr (SPLIT) MICA_BLOAD43_SP_HA(cur.w); else MICA_BLOAD43_H(0, cur.w);
     {
         const int dma_w = wave, dma_l = dma_lane;
 #pragma unroll
@@ -315,8 +343,9 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
             // A fragment base of step st: pair steps read the hi (bc) or lo (a) planes of tap t in k-groups 0,1 and of tap t' in 2,3;
             // the tap-8 steps read the hi planes in k-groups 0,1 and the lo planes in 2,3
 #define W43_ABASE(st) (A + a_common + (W43_KIND(st) >= 3 ? ((2 * G::PLANE * 16) & himask) + W43_AOFF_TAP(8)                                  \
-                                                         : (W43_PAIRDELTA(W43_PS(st)) & himask) + W43_AOFF_TAP(2 * W43_PS(st)) +                \
-                                                           (W43_KIND(st) == 0 ? 2 * G::PLANE * 16 : 0)))
+                                       : SPLIT ? (sp_pd[W43_PS(st)] & himask) + sp_at[W43_PS(st)] + (W43_KIND(st) == 0 ? 2 * G::PLANE * 16 : 0) \
+                                               : (W43_PAIRDELTA(W43_PS(st)) & himask) + W43_AOFF_TAP(2 * W43_PS(st)) +                          \
+                                                 (W43_KIND(st) == 0 ? 2 * G::PLANE * 16 : 0)))
 #define W43_AFRAG(base, f) (*reinterpret_cast<const half8*>((base) + (f) * G::PZ * 16))
             const char* ab_cur = W43_ABASE(0);
             constexpr int AD = 3;                        // A fragments requested ahead (each feeds 4 MFMAs)
@@ -332,6 +361,16 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                 // per wave at once queue for > 1000 cycles in the vector memory pipeline: cycle stamps, tools/exp/clk43.py): step a requests L
                 // of this pair-step (used in c), step b requests H of the next pair-step (used from its a), x requests L of tap 8, y the
                 // next chunk's first H
+                if constexpr (SPLIT) {
+                    // in flight and NEWER than the set a step waits for: the fragment sets requested since and the slab DMAs issued since
+                    if (st == 0) { MICA_BLOAD43_SP_LA(wcur); W43_WAITN(4, 2); }                                   // HA: complete since the chunk-end wait
+                    else if (st == 1) { MICA_BLOAD43_SP_HB(wcur); }
+                    else if (st == 2) { W43_WAITN(4 + W43_NDMA(0) + W43_NDMA(1), 0); }                          // LA; newer: DMA 0, HB, DMA 1
+                    else if (st == 3) { MICA_BLOAD43_SP_LB(wcur); W43_WAITN(4 + W43_NDMA(1) + W43_NDMA(2), 1); }  // HB; newer: DMA 1, DMA 2, LB
+                    else if (st == 4) { MICA_BLOAD43_SP_HA(wnxt); }                                               // the next chunk's (or item's) HA
+                    else if (st == 5) { MICA_BLOAD43_SP_W4(wcur); W43_WAITN(8 + W43_NDMA(3) + W43_NDMA(4), 0); } // LB; newer: DMA 3, HA', DMA 4, W4
+                    else { W43_WAITN(W43_NDMA(5), 1); }                                                           // W4; newer: DMA 5
+                } else
                 if (kind == 0) {
                     MICA_BLOAD43_L(ps, wcur);
                     if (st == 0) W43_WAITN(4, W43_HSET(0)); else if (st == 3) W43_WAITN(4 + W43_NDMA(1) + W43_NDMA(2), W43_HSET(1));
@@ -348,14 +387,14 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                     MICA_BLOAD43_H(0, wnxt);
                     W43_WAITN(4 + W43_NDMA(12), W43_LSET(4));
                 }
-                static_assert(W43_NDMA(13) == 0, "no slab DMA in the last step: the chunk-end wait leaves exactly the next chunk's first H in flight");
+                static_assert(W43_NDMA(13) == 0 && W43_NDMA(6) == 0, "no slab DMA in the last step: the chunk-end wait leaves exactly the next chunk's first H in flight");
                 __builtin_amdgcn_sched_barrier(0);
                 W43_STAMP(1 + 2 * st);
 #pragma unroll
                 for (int q = 0; q < W43_NDMA(st); ++q) MICA_SLAB_DMA43(nsrc, nxt_off, W43_DMA0(st) + q, org);
                 const char* ab_nxt = ab_cur;
                 if (st + 1 < NS) ab_nxt = W43_ABASE(st + 1);
-                half8 (&b1)[NCT] = bq[(kind == 2 || kind == 4) ? W43_LSET(ps) : W43_HSET(ps)];
+                half8 (&b1)[NCT] = bq[SPLIT ? W43_SPSET(st) : (kind == 2 || kind == 4) ? W43_LSET(ps) : W43_HSET(ps)];
 #ifdef MICA43_PRIO
                 {   // experiments: priorities of the three waves that share a SIMD (wave, wave + 4, wave + 8)
                     const int g3 = wave >> 2;
@@ -386,7 +425,8 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #undef W43_AFRAG
             // the slab DMAs of this chunk are older than the four weight loads (the next chunk's first H) still wanted in flight
             W43_STAMP(30);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // (SPLIT: the next chunk's HA was requested three steps ago and is OLDER than this chunk's last slab DMA: everything drains)
+            if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             W43_STAMP(31);
             __syncthreads();
             W43_STAMP(32);
@@ -397,7 +437,7 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
         asm volatile("s_setprio 0");
 #endif
         // the next item's first weight fragments were requested in the last step: retire them here (the compiler cannot see them in flight)
-        W43_WAIT(0, W43_HSET(0));
+        if constexpr (SPLIT) W43_WAIT(0, 2); else W43_WAIT(0, W43_HSET(0));
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU/LDS readers
 
         // ---- output transform through the idle slab buffer: four passes of 32 columns; T = [z 4][p 6][row 16 = y*8+quad][32 + 4] floats ----
@@ -416,9 +456,9 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
             const int elr = elane & 15, elg = elane >> 4;
             const int P = (items_per_b / nnb) * 4;
 #pragma unroll
-            for (int pass = 0; pass < MICA43_EPI_PASSES; ++pass) {
-                const int c0 = (pass >> 1) * 2;                      // first column tile of the pass
-                const int wq = pass & 1;                             // the channel half (wave group) that writes T
+            for (int pass = 0; pass < (SPLIT ? MICA43_EPI_PASSES / 2 : MICA43_EPI_PASSES); ++pass) {
+                const int c0 = SPLIT ? pass * 2 : (pass >> 1) * 2;   // first column tile of the pass
+                const int wq = SPLIT ? 0 : pass & 1;                 // the wave group that writes T (SPLIT: group 0 writes, group 1 adds)
                 if (wn == wq) {
                     // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg = y*8 + quad of the fragment
 #pragma unroll
@@ -431,9 +471,23 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                     }
                 }
                 __syncthreads();
+                if constexpr (SPLIT) {
+                    // the other tap group's partial sums: one add per address (the sum does not depend on any order)
+                    if (wn == 1) {
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            float* dst = xs + (f * 6 + wp) * REG;
+#pragma unroll
+                            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) atomicAdd(dst + (elg * 4 + i) * RS + c * 16 + elr, acc[f][c0 + c][i]);
+                        }
+                    }
+                    __syncthreads();
+                }
                 if (wave < 8) {
                     const float* src = xs + (fz * 6) * REG + frow * RS + fch * 16 + fcg * 4;
-                    const int n0 = inb * BN + wq * 64 + (pass >> 1) * 32 + fch * 16 + fcg * 4;
+                    const int n0 = SPLIT ? inb * BN + pass * 32 + fch * 16 + fcg * 4 : inb * BN + wq * 64 + (pass >> 1) * 32 + fch * 16 + fcg * 4;
                     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (bias) bv = *reinterpret_cast<const float4*>(bias + n0);
                     const float4 m0 = *reinterpret_cast<const float4*>(src + 0 * REG);
@@ -526,9 +580,15 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #undef MICA_BLOAD43
 #undef MICA_SLAB_DMA43
     // nothing may still be in flight towards this workgroup's registers or LDS when it ends
-    W43_WAIT(0, W43_HSET(0));
+    if constexpr (SPLIT) W43_WAIT(0, 2); else W43_WAIT(0, W43_HSET(0));
 #undef MICA_BLOAD43_H
 #undef MICA_BLOAD43_L
+#undef MICA_BLOAD43_SP_HA
+#undef MICA_BLOAD43_SP_LA
+#undef MICA_BLOAD43_SP_HB
+#undef MICA_BLOAD43_SP_LB
+#undef MICA_BLOAD43_SP_W4
+#undef W43_SPSET
 #undef W43_WAIT
 #undef W43_NDMA
 #undef W43_DMA0
@@ -541,7 +601,8 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #undef W43_PAIRDELTA
 }
 
-bool conv_wino43_eligible(int cout) { return cout % 128 == 0; }
+bool conv_wino43_eligible(int cout) { return cout % 128 == 0 || cout == 64; }
+static int conv_wino43_bn(int cout) { return cout % 128 == 0 ? 128 : 64; }
 
 #ifdef MICA43_CLOCKS
 extern "C" int mica_debug_conv43(unsigned* h_out, int n) {
@@ -552,12 +613,12 @@ extern "C" int mica_debug_conv43(unsigned* h_out, int n) {
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null): f32 [B][P][cout][3].
 int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out,
                        int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
-    if (!conv_wino43_eligible(cout)) { refuse_launch("conv_wino43: cout must be a multiple of 128"); return 0; }
+    if (!conv_wino43_eligible(cout)) { refuse_launch("conv_wino43: cout must be a multiple of 128, or 64"); return 0; }
     if ((int64_t)d.D * d.H * ((d.W + 3) / 4) * 24 * 16 >= (1ll << 31)) { refuse_launch("conv_wino43: tile too large for 32-bit slab offsets"); return 0; }
     int total = 0;
     for (int i = 0; i < s.n; ++i) total += s.chunks[i];
     const int ntx = (d.W + 4 * Geo43::QX - 1) / (4 * Geo43::QX), nty = (d.H + Geo43::TY - 1) / Geo43::TY, ntz = (d.D + Geo43::TZ - 1) / Geo43::TZ,
-              nnb = cout / 128;
+              bn = conv_wino43_bn(cout), nnb = cout / bn;
 #ifdef MICA43_CLOCKS
     const size_t lds = 2 * Geo43::CH_BYTES + 12 * 48 * 4;
 #else
@@ -566,7 +627,8 @@ int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstri
     static PerDeviceOnce once;
     static int cus_of[64] = {0};
     const int dev = once.run([&](int dv) {
-        (void)hipFuncSetAttribute((const void*)conv_wino43_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_wino43_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_wino43_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipDeviceProp_t prop;
         int c = 0;
         if (hipGetDeviceProperties(&prop, dv) == hipSuccess) c = prop.multiProcessorCount;
@@ -576,19 +638,22 @@ int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstri
     const int cus = cus_of[dev];
     const int items_per_b = ntx * nty * ntz * nnb, total_items = items_per_b * B;
     const int nwg = total_items >= cus ? cus : ((total_items + 7) / 8) * 8;
-    hipLaunchKernelGGL(conv_wino43_kernel, dim3(nwg), dim3(768), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout, total, ntx,
-                       nty, nnb, items_per_b, total_items, stats_ws);
+    if (bn == 128)
+        hipLaunchKernelGGL(conv_wino43_kernel<128>, dim3(nwg), dim3(768), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout, total, ntx,
+                           nty, nnb, items_per_b, total_items, stats_ws);
+    else
+        hipLaunchKernelGGL(conv_wino43_kernel<64>, dim3(nwg), dim3(768), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout, total, ntx,
+                           nty, nnb, items_per_b, total_items, stats_ws);
     return ntx * nty * ntz * 4;
 }
 
 // ------------------------------------------------------------------------------------------------
-// weights for conv_wino43: [B][nb = Cout/128][chunk][pair-step 5][p 6][unit 8][128][8] halves; unit u: 0,1 = hi of tap t (k-half
+// weights for conv_wino43: [B][nb = Cout/bn][chunk][pair-step 5][p 6][unit 8][bn][8] halves, bn = 128 (64 for Cout = 64); unit u: 0,1 = hi of tap t (k-half
 // 0,1), 2,3 = hi of tap t' = t+1, 4,5 = lo of tap t, 6,7 = lo of tap t'; pair-step 4 is tap 8 alone (units 2,3,6,7 zero).
 // The weight transform u_p = sum_k G[p][k] g_k is done in f64 and rounded once to f32 before the power-of-two scaling.
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_weights_wino43_kernel(const float* __restrict__ w, int cout, int cin, Segs43 sg, int total_chunks,
-                                           const float* __restrict__ cin_scale, float mul, _Float16* __restrict__ wpk, int64_t per_b) {
-    constexpr int bn = 128;
+                                           const float* __restrict__ cin_scale, float mul, _Float16* __restrict__ wpk, int64_t per_b, int bn) {
     const int b = blockIdx.y;
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [nb][chunk][ps 5][p 6][unit 8][n in block]
     int64_t total = (int64_t)total_chunks * 5 * 6 * 8 * cout;
@@ -654,7 +719,7 @@ void launch_pack_weights_wino43(const float* w, int cout, int cin, const int* h_
     const int64_t total = (int64_t)total_chunks * 5 * 48 * cout;
     dim3 grid((unsigned)((total + 255) / 256), B);
     hipLaunchKernelGGL(pack_weights_wino43_kernel, grid, dim3(256), 0, st, w, cout, cin, sg, total_chunks, cin_scale, cout_scale * wscale,
-                       wpk, packed_weight_halves_wino43(cout, total_chunks));
+                       wpk, packed_weight_halves_wino43(cout, total_chunks), conv_wino43_bn(cout));
 }
 
 // ------------------------------------------------------------------------------------------------

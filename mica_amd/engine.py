@@ -28,7 +28,8 @@ class Engine:
         (`forward_logits`: MICA.forward is size-agnostic).
         conv_variant: None = the library default (1, or MICA_F43 from the environment), 0 = every 3x3x3 conv on the F(2,3) kernel,
         1 = encoder.2's four 3x3x3 convs on the F(4,3) kernel, 2 = those and encoder.1's transition (+0.7 % throughput, rms error
-        +1-2 %).  Fixed before the weights are loaded."""
+        +1-2 %), 3 = mode 1 and the late narrow layers (FPN smooth convs, the heads' conv1) on the kernel's 64-channel variant.
+        Fixed before the weights are loaded."""
         if not torch.cuda.is_available():
             raise MicaHipError("no HIP device visible: mica_amd runs on MI355X (gfx950) only, there is no CPU fallback")
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
@@ -40,8 +41,8 @@ class Engine:
         self.tile_shape = tuple(int(v) for v in tile_size) if isinstance(tile_size, (tuple, list)) else (int(tile_size),) * 3
         if len(self.tile_shape) != 3:
             raise MicaHipError(f"tile_size must be an int or (D, H, W), got {tile_size!r}")
-        if conv_variant is not None and int(conv_variant) not in (0, 1, 2):       # before the context (tens of GB of workspace) exists
-            raise MicaHipError(f"conv_variant must be None, 0, 1 or 2, got {conv_variant!r}")
+        if conv_variant is not None and int(conv_variant) not in (0, 1, 2, 3):    # before the context (tens of GB of workspace) exists
+            raise MicaHipError(f"conv_variant must be None, 0, 1, 2 or 3, got {conv_variant!r}")
         self.tile_size = self.tile_shape[0] if len(set(self.tile_shape)) == 1 else None      # None: non-cubic, forward_logits only
         h = C.c_void_p()
         with torch.cuda.device(self.device):          # the ambient current device of the caller is left alone

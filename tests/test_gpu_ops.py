@@ -79,9 +79,19 @@ def test_fused_norm_conv1x1_into_winograd_conv(eng, cin, cmid, cout, dims, batch
     (130, 256, (3, 64, 64), 1),             # production width, items > workgroups
     (3, 128, (1, 1, 1), 3),                 # a single voxel
     (48, 128, (2, 3, 66), 1),               # W > 64
+    # the 64-channel variant (round 5): the two wave groups split the taps, partial sums added in the epilogue
+    (64, 64, (8, 8, 8), 2),                 # FPN smooth conv's channels; four chunks
+    (16, 64, (4, 4, 16), 1),                # one chunk, one tile
+    (192, 64, (6, 10, 20), 1),              # backbone head conv1: 12 chunks, ragged tiles
+    (196, 64, (8, 8, 16), 2),               # ca head conv1: 13 chunks (odd), padded last chunk
+    (200, 64, (5, 7, 9), 1),                # aa head conv1; ragged quad
+    (64, 64, (3, 64, 64), 1),               # production width, items > workgroups
+    (24, 64, (16, 32, 16), 2),              # the blocked tile walk
+    (5, 64, (1, 1, 1), 2),                  # a single voxel
 ])
 def test_conv3d_winograd_f43_kernel(eng, cin, cout, dims, batch):
-    """conv_wino43_kernel (kernels_conv43.hip: Winograd F(4,3) along x, the kernel of encoder.2's convs) as a single op against
+    """conv_wino43_kernel<128 | 64> (kernels_conv43.hip: Winograd F(4,3) along x, the kernel of encoder.2's convs and - its tap-split
+    64-channel variant - of the FPN smooth convs and the heads' conv1) as a single op against
     torch's conv3d: operand producer, weight packer, 6-position slab, output transform, ragged tiles, persistent item walk."""
     x = _rand((batch, cin, *dims), 31)
     w = _rand((cout, cin, 3, 3, 3), 32) * (3.0 / (cin * 27)) ** 0.5
@@ -89,6 +99,31 @@ def test_conv3d_winograd_f43_kernel(eng, cin, cout, dims, batch):
     ref = F.conv3d(x, w, b, padding=1)
     got = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3, variant=1)
     assert rel_err(got, ref) < RTOL
+
+
+def test_conv3d_winograd_f43_tap_split_variant_asymmetric_deltas_and_determinism(eng):
+    """The 64-channel variant: delta inputs with asymmetric weights (a tap assigned to the wrong wave group, a swapped pair-step or a
+    wrong tap-8 half shows at once), and bitwise determinism of the partial-sum meeting (one LDS add per address)."""
+    x = torch.zeros((1, 32, 8, 8, 16))
+    x[0, 3, 2, 5, 7] = 1.0
+    x[0, 27, 6, 1, 12] = -2.0
+    x[0, 5, 0, 0, 0] = 0.5
+    x[0, 17, 7, 7, 15] = 3.0
+    w = torch.arange(64 * 32 * 27, dtype=torch.float32).reshape(64, 32, 3, 3, 3) / 4000.0
+    b = torch.arange(64, dtype=torch.float32)
+    ref = F.conv3d(x, w, b, padding=1)
+    got = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3, variant=1)
+    assert rel_err(got, ref) < 2e-5
+    x = _rand((2, 196, 8, 16, 32), 5, 0.0, 4.0)
+    w = _rand((64, 196, 3, 3, 3), 6) * 0.03
+    b = _rand((64,), 7)
+    a1 = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3, variant=1)
+    a2 = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3, variant=1)
+    assert torch.equal(a1, a2)
+    ref64 = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    e43, e23 = rel_err(a1, ref64), rel_err(eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3, variant=0), ref64)
+    print(f"196->64 vs float64: F(4,3) tap-split {e43:.2e}, F(2,3) {e23:.2e}")
+    assert e43 < 2e-5
 
 
 def test_conv3d_winograd_f43_asymmetric_identity_and_precision(eng):
@@ -343,5 +378,5 @@ def test_engine_refuses_a_bad_conv_variant_before_it_allocates():
     from mica_amd.engine import Engine, MicaHipError
     free0 = torch.cuda.mem_get_info(0)[0]
     with pytest.raises(MicaHipError, match="conv_variant"):
-        Engine(0, max_batch=2, tile_size=64, conv_variant=3)
+        Engine(0, max_batch=2, tile_size=64, conv_variant=7)
     assert torch.cuda.mem_get_info(0)[0] >= free0 - (64 << 20)

@@ -2,7 +2,8 @@
 
 For each fixture: scaled max error, rms of the scaled error and the fraction of voxels beyond 1e-4 literal relative error, against the
 reference module's float32 logits and - where the fixture has them - against its float64 logits, for conv variant 0 (every 3x3x3 conv on
-the F(2,3) kernel) and variant 1 (encoder.2 on the F(4,3) kernel: the shipped default).  usage: python tools/parity_margins.py > out.txt"""
+the F(2,3) kernel), variant 1 (encoder.2 on the F(4,3) kernel) and variant 3 (that and the late narrow layers on its 64-channel variant).
+usage: python tools/parity_margins.py [variants, e.g. 0,1,3] > out.txt"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,6 +11,7 @@ from mica_amd.engine import AF_BATCH, AF_PER_TILE, Engine
 from mica_amd.synth import CASES64, case64, stress_case, synth_af, synth_density
 from mica_amd.weights import synth_state_dict
 
+VARIANTS = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 else (0, 1, 3)
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
@@ -40,14 +42,14 @@ print("fixture                            variant  against        scaled max bb 
 for tag, gname, ws, wg in (("w2022g6", "model_S16_af.npz", 2022, 6.0), ("w7g3", "model_S16_af_w7g3.npz", 7, 3.0), ("w99g10", "model_S16_af_w99g10.npz", 99, 10.0)):
     g, t = np.load(os.path.join(G, gname)), np.load(os.path.join(G, f"truth64_S16_{tag}.npz"))
     x, af = synth_density((1, 1, 16, 16, 16), int(g["seed"])), synth_af((16, 16, 16), int(g["seed"]), float(g["afp"]))[None]
-    for v in (0, 1):
+    for v in VARIANTS:
         out = run(synth_state_dict(ws, wg), x, af, 16, AF_BATCH, v)
         line(f"S16 {tag}", v, "reference f32", out, [g[k] for k in ("bb", "ca", "aa")])
         line(f"S16 {tag}", v, "float64 truth", out, [t[k] for k in ("bb", "ca", "aa")], "reference f32 vs truth max " + " / ".join(f"{a:.2e}" for a in t["ref32_scaled"]))
 for kind in ("heavy", "blob"):
     g = np.load(os.path.join(G, f"r4_{kind}_S16.npz"))
     w, x, af = stress_case(kind, 16)
-    for v in (0, 1):
+    for v in VARIANTS:
         out = run(w, x, af, 16, AF_BATCH, v)
         line(f"S16 r4_{kind}", v, "reference f32", out, [g[k] for k in ("bb", "ca", "aa")])
         line(f"S16 r4_{kind}", v, "float64 truth", out, [g[k] for k in ("bb64", "ca64", "aa64")], "reference f32 vs truth max " + " / ".join(f"{a:.2e}" for a in g["ref32_scaled"]))
@@ -55,7 +57,7 @@ for case in CASES64:
     g = np.load(os.path.join(G, f"truth64_S64_sub_{case}.npz"))
     st = int(g["stride"])
     w, x, af = case64(case)
-    for v in (0, 1):
+    for v in VARIANTS:
         out = [o[..., ::st, ::st, ::st] for o in run(w, x, af, 64, AF_PER_TILE, v)]
         line(f"S64 {case} (stride-4 subsample)", v, "reference f32", out, [g[k] for k in ("bb", "ca", "aa")],
              "reference 1 vs 8 threads rel>1e-4 " + " / ".join(f"{a:.3f}" for a in g["floor_frac_rel"]))
