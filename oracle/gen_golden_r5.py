@@ -14,7 +14,8 @@ tile:
 Written per case: tests/golden/truth64_S64_sub_<case>.npz = the float64 logits on the stride-4 subsample the other 64^3 fixtures
 use (bb64 / ca64 / aa64), the float32 logits on the same subsample (bb / ca / aa), and the reference float32 path's own distances
 from the truth on that subsample (`ref32_scaled`, `ref32_rms`, `ref32_frac_rel` = its fraction of voxels beyond 1e-4 literal relative
-error; `floor_frac_rel` = the same fraction between its 1-thread and 8-thread runs) - what the GPU path is bounded by.  The
+error; `floor_scaled` / `floor_frac_rel` = scaled max difference and that fraction between its 1-thread and 8-thread runs) - what the
+GPU path is bounded by.  The
 manifest (tests/golden/manifest.json["S64"]) keeps, per case and head, on the WHOLE tile and on the subsample: scaled max, rms of
 the scaled error and the fraction of voxels beyond 1e-4 true relative error, for reference-f32 vs truth and for 1 vs 8 threads.
 
@@ -95,6 +96,7 @@ def gen(case, manifest):
               "bb": sub(r8[0]), "ca": sub(r8[1]), "aa": sub(r8[2]),
               "ref32_scaled": np.array([rec["reference_f32_vs_truth"][n]["sub"]["scaled"] for n in ("bb", "ca", "aa")]),
               "ref32_rms": np.array([rec["reference_f32_vs_truth"][n]["sub"]["rms"] for n in ("bb", "ca", "aa")]),
+              "floor_scaled": np.array([rec["threads_1_vs_8"][n]["sub"]["scaled"] for n in ("bb", "ca", "aa")]),
               "floor_frac_rel": np.array([rec["threads_1_vs_8"][n]["sub"]["frac_rel_gt_1e-4"] for n in ("bb", "ca", "aa")]),
               "ref32_frac_rel": np.array([rec["reference_f32_vs_truth"][n]["sub"]["frac_rel_gt_1e-4"] for n in ("bb", "ca", "aa")]),
               "S": 64, "stride": ST}
