@@ -36,8 +36,8 @@
 // as conv_wino16_kernel<64>, the two wave groups own the SAME 64 channels and SPLIT THE TAPS - group 0 taps 0..3 and the hi x hi /
 // lo x hi products of tap 8 ("x"), group 1 taps 4..7 and tap 8's hi x lo product ("y") - seven steps per chunk each instead of
 // fourteen; per-wave tile, operand reuse and weight bytes per MFMA stay those of the 128 variant.  One instruction stream serves
-// both groups (tap offsets and weight offsets are per-group scalars); the partial sums meet in the epilogue: group 0 stores its
-// accumulators into the transform tile, group 1 adds its own (ds_add_f32, one add per address: deterministic).  Oracle:
+// both groups (tap offsets and weight offsets are per-group scalars); the partial sums meet in the epilogue: group 1 stores its
+// accumulators into the transform tile, group 0 adds its own to them in place (one add per address: deterministic).  Oracle:
 // oracle/wino_network.py f43s@late (profiles/r05_wino_late_numerics.txt): the rms distance from the float64 truth moves by < 1.5 %.
 #include "common.h"
 #include <cstdio>
@@ -189,8 +189,10 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #define W43_AOFF_TAP(tap) ((((tap) / 3) * G::PZ + ((tap) % 3) * G::QX) * 16)
 #define W43_PAIRDELTA(ps) ((ps) == 1 ? (G::PZ - 2 * G::QX) * 16 : G::QX * 16)
     // slab DMA slots per wave and step (the first six steps of a chunk), and the first DMA index of a step
-#define W43_NDMA(st) ((st) >= 0 && (st) < 6 ? DPS : 0)
-#define W43_DMA0(st) ((st) * DPS)
+    // (SPLIT: a chunk is seven steps, half as long: the six DMAs go out in its first three steps, two each, so that the last of them
+    // has four steps to land before the chunk-end wait - with one per step it had one, and the wait exposed the HBM latency every chunk)
+#define W43_NDMA(st) (SPLIT ? ((st) >= 0 && (st) < 3 ? 2 * DPS : 0) : ((st) >= 0 && (st) < 6 ? DPS : 0))
+#define W43_DMA0(st) (SPLIT ? (st) * 2 * DPS : (st) * DPS)
     // one fragment set: four 16-cout column tiles, 256 B apart; `delta` (bytes, applied to k-groups 2,3) selects the second tap's units
 #define MICA_BLOAD43(set, base, off, delta)                                                                             \
     do {                                                                                                                \
@@ -213,8 +215,8 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     // wait until at most n (a compile-time constant after unrolling, 4 .. 14) vector-memory operations are outstanding
 #define W43_WAITN(n, set)                                                                                               \
     do {                                                                                                                \
-        static_assert((n) >= 1 && (n) <= 14, "wait immediates");                                                        \
-        if ((n) == 1) W43_WAIT(1, set); else if ((n) == 4) W43_WAIT(4, set); else if ((n) == 5) W43_WAIT(5, set); else if ((n) == 6) W43_WAIT(6, set);       \
+        static_assert((n) >= 0 && (n) <= 14, "wait immediates");                                                        \
+        if ((n) == 0) W43_WAIT(0, set); else if ((n) == 1) W43_WAIT(1, set); else if ((n) == 4) W43_WAIT(4, set); else if ((n) == 5) W43_WAIT(5, set); else if ((n) == 6) W43_WAIT(6, set);       \
         else if ((n) == 7) W43_WAIT(7, set); else if ((n) == 8) W43_WAIT(8, set); else if ((n) == 9) W43_WAIT(9, set);  \
         else if ((n) == 10) W43_WAIT(10, set); else if ((n) == 11) W43_WAIT(11, set); else if ((n) == 12) W43_WAIT(12, set); \
         else if ((n) == 13) W43_WAIT(13, set); else W43_WAIT(14, set);                                                  \
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #pragma unroll
             for (int pass = 0; pass < (SPLIT ? MICA43_EPI_PASSES / 2 : MICA43_EPI_PASSES); ++pass) {
                 const int c0 = SPLIT ? pass * 2 : (pass >> 1) * 2;   // first column tile of the pass
-                const int wq = SPLIT ? 0 : pass & 1;                 // the wave group that writes T (SPLIT: group 0 writes, group 1 adds)
+                const int wq = SPLIT ? 1 : pass & 1;                 // the wave group that writes T first (SPLIT: group 1, then group 0 adds its own)
                 if (wn == wq) {
                     // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg = y*8 + quad of the fragment
 #pragma unroll
@@ -472,15 +474,17 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                 }
                 __syncthreads();
                 if constexpr (SPLIT) {
-                    // the other tap group's partial sums: one add per address (the sum does not depend on any order)
-                    if (wn == 1) {
+                    // the partial sums of the two tap groups meet: wave (wp, 0) reads what wave (wp, 1) stored at the very same addresses,
+                    // adds its own and writes the sum back (plain LDS reads and writes: LDS atomics ran at a fraction of their rate -
+                    // 35 us per item against 8, tools/exp/conv64_ab.sh)
+                    if (wn == 0) {
 #pragma unroll
                         for (int f = 0; f < NF; ++f) {
                             float* dst = xs + (f * 6 + wp) * REG;
 #pragma unroll
                             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) atomicAdd(dst + (elg * 4 + i) * RS + c * 16 + elr, acc[f][c0 + c][i]);
+                                for (int i = 0; i < 4; ++i) dst[(elg * 4 + i) * RS + c * 16 + elr] += acc[f][c0 + c][i];
                         }
                     }
                     __syncthreads();
