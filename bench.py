@@ -386,6 +386,7 @@ def main():
         dms, dl, dbytes = eng.profile(1)
         wms, wl, wflops = eng.profile(2)
         eng43 = eng.profile(5)
+        e64ms, e64l, e64flops = eng.profile(6)
         eng.set_profiling(False)
         # counter figures come from the committed rocprofv3 passes of tools/profile.sh (profiles/rNN_pmc_traffic.json,
         # rNN_pmc_sq_summary.txt); each is stamped with the hash of the library sources it was collected on and is quoted only
@@ -422,16 +423,21 @@ def main():
         w16 = mfma_obj("conv_wino16_kernel<128|64|32>: Winograd F(2,3)-x, the 3x3x3 convs outside encoder.2", "conv_wino16_kernel", wach,
                        WINO_MFMA_PER_ALGORITHMIC, wms, wl, wflops, ["conv_wino16_kernel<128>", "conv_wino16_kernel<64>", "conv_wino16_kernel<32>"])
         if fl > 0:
-            roof = mfma_obj("conv_wino43_kernel: the four 3x3x3 convs of encoder.2 (68 % of the network's FLOPs) via Winograd F(4,3)-x, split-f16 x3 "
-                            "MFMA (v_mfma_f32_16x16x32_f16)", "conv_wino43_kernel", fach, WINO43_MFMA_PER_ALGORITHMIC, fms, fl, fflops, ["conv_wino43_kernel"])
+            roof = mfma_obj("conv_wino43_kernel<128>: the four 3x3x3 convs of encoder.2 (68 % of the network's FLOPs) via Winograd F(4,3)-x, split-f16 x3 "
+                            "MFMA (v_mfma_f32_16x16x32_f16)", "conv_wino43_kernel<128>", fach, WINO43_MFMA_PER_ALGORITHMIC, fms, fl, fflops,
+                            ["conv_wino43_kernel<128>", "conv_wino43_kernel"])
             roof["conv_wino16"] = w16
+            if e64l > 0:
+                roof["conv_wino43_64"] = mfma_obj("conv_wino43_kernel<64>: the tap-split 64-channel variant - FPN smooth convs, the heads' conv1 (operand-stream-"
+                                                  "bound, not MFMA-bound: profiles/r05_f43_late_ab.txt)", "conv_wino43_kernel<64>", e64flops / (e64ms * 1e-3) / 1e12,
+                                                  WINO43_MFMA_PER_ALGORITHMIC, e64ms, e64l, e64flops, ["conv_wino43_kernel<64>"])
         else:
             roof = w16
-        ex_all = (wflops * WINO_MFMA_PER_ALGORITHMIC + fflops * WINO43_MFMA_PER_ALGORITHMIC) / max((wms + fms) * 1e-3, 1e-12) / 1e12
+        ex_all = (wflops * WINO_MFMA_PER_ALGORITHMIC + (fflops + e64flops) * WINO43_MFMA_PER_ALGORITHMIC) / max((wms + fms + e64ms) * 1e-3, 1e-12) / 1e12
         roof = dict({"bound": "mfma"}, **roof)
-        roof["all_3x3x3_convs"] = {"launches_per_batch": wl + fl, "ms_per_batch": wms + fms, "achieved": ex_all, "peak": PEAK_F16_MFMA_TF,
+        roof["all_3x3x3_convs"] = {"launches_per_batch": wl + fl + e64l, "ms_per_batch": wms + fms + e64ms, "achieved": ex_all, "peak": PEAK_F16_MFMA_TF,
                                    "frac": ex_all / PEAK_F16_MFMA_TF,
-                                   "algorithmic_tflops": (wflops + fflops) / max((wms + fms) * 1e-3, 1e-12) / 1e12}
+                                   "algorithmic_tflops": (wflops + fflops + e64flops) / max((wms + fms + e64ms) * 1e-3, 1e-12) / 1e12}
         roof["all_dense_convs"] = {"algorithmic_tflops": ach_all, "launches_per_batch": launches, "ms_per_batch": ms,
                                    "note": "3x3x3 and 1x1x1 launches together (the 1x1 kernel is HBM-bound and also does the operand passes)"}
         roof["profile_source"] = {"library_source_hash": here, "traffic": tnote, "counters": sqnote}

@@ -82,11 +82,12 @@ int mica_load_weight(mica_ctx* ctx, const char* name, const float* h_data, const
 int mica_finalize_weights(mica_ctx* ctx);
 
 /* Which dense 3x3x3 convs run on the Winograd F(4,3)-along-x kernel (1.33x fewer MFMAs, ~4x the per-layer rounding error) instead
- * of F(2,3): 0 = none; 1 = the four convs of encoder.2 (models/model.py:107,115,122,142 at C = 256: 68 % of the network's FLOPs) -
- * the default: whole-network error indistinguishable from mode 0 (profiles/r04_wino_network_numerics.txt); 2 = those and encoder.1's
+ * of F(2,3): 0 = none; 1 = the four convs of encoder.2 (models/model.py:107,115,122,142 at C = 256: 68 % of the network's FLOPs):
+ * whole-network error indistinguishable from mode 0 (profiles/r04_wino_network_numerics.txt); 2 = those and encoder.1's
  * transition conv (128 -> 256, 6 % of the FLOPs: +0.7 % throughput, rms error +1-2 %, profiles/r04_f43_ab_bench.txt); 3 = mode 1 and
  * the late narrow layers - the FPN's three smooth convs (64 -> 64) and the heads' conv1 (192 / 196 / 200 -> 64, models/model.py:165-174,
- * 210) - on the kernel's 64-channel variant (the two wave groups split the taps; profiles/r05_wino_late_numerics.txt).  Also settable
+ * 210) - on the kernel's 64-channel variant (the two wave groups split the taps) - the DEFAULT since round 5: +1.1 % throughput, rms
+ * distance from the float64 result within 1.5 % of mode 1's (profiles/r05_wino_late_numerics.txt, r05_f43_late_ab.txt).  Also settable
  * through the environment (MICA_F43=0|1|2|3, read by mica_create).  The variant decides how weights are packed: before
  * mica_finalize_weights.                                                                                                            */
 int mica_set_conv_variant(mica_ctx* ctx, int mode);
@@ -293,7 +294,7 @@ int mica_get_conv_profile(mica_ctx* ctx, double* h_ms_total, int64_t* h_launches
 /* kind 0 = dense conv launches (work = algorithmic FLOPs; = kinds 2 + 4), kind 1 = depthwise conv3d launches (work =
  * algorithmic HBM bytes, 8 B per voxel and channel), kind 2 = 3x3x3 convs on the F(2,3) kernel, kind 3 = operand passes
  * (InstanceNorm apply + ReLU + re-encode; work = algorithmic bytes), kind 4 = 1x1x1 convs only, kind 5 = 3x3x3 convs on the
- * F(4,3) kernel (kind 0 = kinds 2 + 4 + 5).                                                       */
+ * F(4,3) kernel with 128-channel blocks (encoder.2), kind 6 = on its tap-split 64-channel variant (kind 0 = kinds 2 + 4 + 5 + 6).   */
 int mica_get_profile(mica_ctx* ctx, int kind, double* h_ms_total, int64_t* h_launches, double* h_work);
 
 #ifdef __cplusplus

@@ -62,7 +62,7 @@ struct Head {
 
 }  // namespace
 
-constexpr int PROF_KINDS = 6;
+constexpr int PROF_KINDS = 7;
 
 struct mica_ctx {
     int device = 0, maxB = 1, S = 64;
@@ -100,16 +100,16 @@ struct mica_ctx {
     int* d_err = nullptr;            // range flags, one per tile of the call (int[maxB])
     int* cur_err = nullptr;          // ... of the run of tiles forward_run is working on
     float ascale = ASCALE_DEFAULT;   // activation scale of the split encoding (common.h) every forward call starts from
-    int f43_mode = 1;                // 0: every 3^3 conv on the F(2,3) kernel; 1 (default): encoder.2's four convs on the F(4,3) kernel; 2: those and
-                                     // encoder.1's transition; 3: mode 1 and the late narrow layers (FPN smooth x3, the heads' conv1 x3) on its
-                                     // 64-channel variant
+    int f43_mode = 3;                // 0: every 3^3 conv on the F(2,3) kernel; 1: encoder.2's four convs on the F(4,3) kernel; 2: those and
+                                     // encoder.1's transition; 3 (default since round 5): mode 1 and the late narrow layers (FPN smooth x3, the
+                                     // heads' conv1 x3) on its 64-channel variant
     float last_scale = ASCALE_DEFAULT;   // the lowest scale a tile of the last forward call needed (forward_checked)
     int last_retries = 0;                // tiles of the last forward call that had to be repeated at a lower scale
     std::vector<char> use_af;        // per tile of the last forward_impl call: AF3 branch taken
     float* h_abs = nullptr;       // pinned
     int* h_err = nullptr;         // pinned
 
-    // profiling: HIP events around the launches of kind 0 = every dense conv (= kinds 2 + 4, work = FLOPs), 1 = depthwise
+    // profiling: HIP events around the launches of kind 0 = every dense conv (= kinds 2 + 4 + 5 + 6, work = FLOPs), 1 = depthwise
     // conv3d (work = bytes), 2 = 3^3 convs (Winograd kernel), 3 = operand passes (prep kernels, work = bytes), 4 = 1x1 convs
     bool profiling = false;
     std::vector<hipEvent_t> ev;
@@ -304,11 +304,12 @@ void prof_end(mica_ctx* c, int kind, double work, hipStream_t st) {
 // produced too (fused into the kernel's epilogue, merged by stats_finalize).
 void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, hipStream_t st, float* mean = nullptr,
               float* rstd = nullptr) {
-    prof_begin(c, L.f43 ? 5 : 2, st);
+    const int pk = !L.f43 ? 2 : L.cout % 128 == 0 ? 5 : 6;       // F(2,3) kernel | F(4,3) kernel, 128-channel blocks | its tap-split 64-channel variant
+    prof_begin(c, pk, st);
     const int P = L.f43 ? launch_conv_wino43(src.s, L.d_wpk, 0, L.d_b, 1.0f / (L.wscale * (c->ascale / WINO43_ASCALE_DIV)), out, B, c->d, L.cout,
                                              mean ? c->ws : nullptr, st)
                         : launch_conv_wino(src.s, L.d_wpk, 0, L.d_b, 1.0f / (L.wscale * c->ascale), out, B, c->d, L.cout, mean ? c->ws : nullptr, st);
-    prof_end(c, L.f43 ? 5 : 2, L.flops_per_voxel * (double)c->V * B, st);
+    prof_end(c, pk, L.flops_per_voxel * (double)c->V * B, st);
     if (mean) launch_stats_finalize(c->ws, B, P, L.cout, 1e-5f, mean, rstd, st);
 }
 
@@ -519,7 +520,8 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
             ms[c->ev_kind[i]] += t;
             n[c->ev_kind[i]]++;
         }
-        ms[0] = ms[2] + ms[4] + ms[5]; n[0] = n[2] + n[4] + n[5]; c->prof_work[0] = c->prof_work[2] + c->prof_work[4] + c->prof_work[5];
+        ms[0] = ms[2] + ms[4] + ms[5] + ms[6]; n[0] = n[2] + n[4] + n[5] + n[6];
+        c->prof_work[0] = c->prof_work[2] + c->prof_work[4] + c->prof_work[5] + c->prof_work[6];
         for (int k = 0; k < PROF_KINDS; ++k) { c->last_ms[k] = ms[k]; c->last_launches[k] = n[k]; c->last_work[k] = c->prof_work[k]; }
     }
     return MICA_OK;
@@ -633,7 +635,7 @@ int mica_create_dims(int device, int max_batch, int td, int th, int tw, mica_ctx
     }
     mica_ctx* c = new mica_ctx();
     if (const char* ev = getenv("MICA_STEM_MFMA")) c->stem_mode = atoi(ev) != 0;
-    if (const char* ev = getenv("MICA_F43")) { const int m = atoi(ev); c->f43_mode = m < 0 || m > 3 ? 1 : m; }      // A/B switch (0: the F(2,3) kernel everywhere)
+    if (const char* ev = getenv("MICA_F43")) { const int m = atoi(ev); c->f43_mode = m < 0 || m > 3 ? 3 : m; }      // A/B switch (0: the F(2,3) kernel everywhere)
     c->device = device;
     c->maxB = max_batch;
     c->S = tile_size;

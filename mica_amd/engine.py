@@ -26,7 +26,7 @@ class Engine:
     def __init__(self, device: int | str | torch.device = 0, max_batch: int = 1, tile_size=64, conv_variant: int | None = None):
         """tile_size: an int (cubic tiles, what the tiler / predictor use) or (D, H, W) for the inner boundary alone
         (`forward_logits`: MICA.forward is size-agnostic).
-        conv_variant: None = the library default (1, or MICA_F43 from the environment), 0 = every 3x3x3 conv on the F(2,3) kernel,
+        conv_variant: None = the library default (3, or MICA_F43 from the environment), 0 = every 3x3x3 conv on the F(2,3) kernel,
         1 = encoder.2's four 3x3x3 convs on the F(4,3) kernel, 2 = those and encoder.1's transition (+0.7 % throughput, rms error
         +1-2 %), 3 = mode 1 and the late narrow layers (FPN smooth convs, the heads' conv1) on the kernel's 64-channel variant.
         Fixed before the weights are loaded."""

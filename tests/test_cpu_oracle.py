@@ -359,22 +359,25 @@ def test_inline_asm_weight_prefetch_of_the_f43_kernel_is_hazard_free(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", asm, src],
                           stderr=subprocess.DEVNULL)
     text = open(asm).read()
-    m = re.search(r"^_ZN4mica18conv_wino43_kernelE.*?s_endpgm", text, flags=re.S | re.M)
-    assert m
-    body = m.group(0)
-    part = str(tmp_path / "wino43.s")
-    open(part, "w").write(body)
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), part], text=True)
-    assert "violations: 0" in out, out[-2000:]
-    assert body.count("v_mfma_f32_16x16x32_f16") == 224 and "scratch_" not in body
-    # the chunk loop: from the first to the last MFMA
-    lines = body.split("\n")
-    idx = [i for i, l in enumerate(lines) if "v_mfma_f32_16x16x32_f16" in l]
-    loop = "\n".join(lines[idx[0] - 120:idx[-1] + 1])
-    assert loop.count("global_load_lds_dwordx4") == 6
-    assert loop.count("ds_read_b128") + loop.count("ds_load_b128") in (36, 37, 38, 39)        # 36 per chunk; the first few may sit above the window
-    loads = len(re.findall(r"global_load_dwordx4", loop))
-    assert loads == 40, loads
+    # <128>: 14 steps per chunk and wave; <64> (round 5, the tap-split variant): 7 steps, five fragment sets in the same three register
+    # sets (20 asm loads), the same six slab DMAs, 20 A-fragment reads
+    for bn, mfmas, loads_want, reads_want in ((128, 224, 40, (36, 37, 38, 39)), (64, 112, 20, (20, 21, 22, 23))):
+        m = re.search(r"^_ZN4mica18conv_wino43_kernelILi%dEE.*?s_endpgm" % bn, text, flags=re.S | re.M)
+        assert m, bn
+        body = m.group(0)
+        part = str(tmp_path / f"wino43_{bn}.s")
+        open(part, "w").write(body)
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py"), part], text=True)
+        assert "violations: 0" in out, out[-2000:]
+        assert body.count("v_mfma_f32_16x16x32_f16") == mfmas and "scratch_" not in body
+        # the chunk loop: from the first to the last MFMA
+        lines = body.split("\n")
+        idx = [i for i, l in enumerate(lines) if "v_mfma_f32_16x16x32_f16" in l]
+        loop = "\n".join(lines[idx[0] - 120:idx[-1] + 1])
+        assert loop.count("global_load_lds_dwordx4") == 6
+        assert loop.count("ds_read_b128") + loop.count("ds_load_b128") in reads_want      # the first few may sit above the window
+        loads = len(re.findall(r"global_load_dwordx4", loop))
+        assert loads == loads_want, (bn, loads)
     spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
     assert spills and max(spills) == 0, spills
 

@@ -13,6 +13,9 @@ def short(n):
     m = re.search(r"conv_wino16_kernelILi(\d+)E", n)
     if m:
         return "conv_wino16_kernel<%s>" % m.group(1)
+    m = re.search(r"conv_wino43_kernelILi(\d+)E", n) or re.search(r"conv_wino43_kernel<(\d+)>", n)
+    if m:
+        return "conv_wino43_kernel<%s>" % m.group(1)
     m = re.search(r"conv2_kernelILi(\d+)ELi(\d+)E", n)
     if m:
         return "conv2_kernel<%s,%s>" % (m.group(1), m.group(2))

@@ -12,6 +12,10 @@ def load(path, counter):
     return per
 
 def short(n):
+    import re
+    m = re.search(r"conv_wino43_kernelILi(\d+)E", n) or re.search(r"conv_wino43_kernel<(\d+)>", n)
+    if m:
+        return "conv_wino43_kernel<%s>" % m.group(1)
     for key in ("conv_wino43_kernel", "prep_wino43_kernel", "stem_mfma_kernel", "conv_wino16_kernel", "conv1x1_kernel", "depthwise_kernel", "prep_wino_kernel", "prep_kernel",
                 "stats_kernel", "stem_kernel", "gather_tiles_kernel", "stitch_tiles_kernel", "postprocess_kernel", "head_final_kernel",
                 "hist_kernel", "finish_kernel"):
