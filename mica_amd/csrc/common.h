@@ -132,6 +132,7 @@ struct Conv1Src {
     int chunks_total;       // chunks per batch entry of the buffer (raw: channels / 16)
     int chunk_off;          // first chunk within the buffer
     int relu;               // raw: ReLU after the normalisation
+    int cblk;               // raw: 0 = plain NDHWC [V][C]; else the blocked raw layout [C / cblk][V][cblk] (below)
 };
 struct Conv1Srcs { Conv1Src s[2]; int n; };
 
@@ -178,8 +179,13 @@ void launch_fill_float(float* p, int64_t n, float v, hipStream_t st);
 // depthwise 3^3 on raw input with fused (x-mean)*rstd, relu, *scale applied on load (zero padding after)
 // C must be a multiple of 16.  stats_ws (nullable): fused InstanceNorm partials, returns their count P.
 // gap_ws (nullable): f32 [B][P][C] per-block sums of the normalised input over the block's own voxels (launch_finalize_sum).
+// cblk (0 = plain NDHWC): x AND out are in the blocked raw layout float [B][C / cblk][V][cblk] - round 5: the two tensors around the
+// depthwise conv (conv3's raw output, its own output) are stored in blocks of 32 channels, so that the 32-channel slab a depthwise
+// workgroup streams and the chunk pair a 1x1 workgroup stages are contiguous runs of memory instead of 128-byte pieces at a pitch of
+// C floats (tools/exp/dw_layout.py: the same kernel at C = 32, where a slab IS the row, streams 11 % faster than at C = 256)
 int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
-                     const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st);
+                     const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st,
+                     int cblk = 0);
 // merge P partials f32 [B][P][C][3] = (count, mean, M2) into mean / rstd.  gate f32 [B][C] (nullable): the statistics are
 // those of u while the tensor that is normalised downstream is t = g u + const (g > 0 per tile and channel): then
 // (t - mean_t) / sqrt(var_t + eps) = (u - mean_u) * g / sqrt(g^2 var_u + eps), i.e. rstd = g / sqrt(g^2 var_u + eps).
@@ -211,7 +217,7 @@ void launch_prep_wino(const float* x, int B, Dims d, int C, const float* mean, c
                       hipStream_t st);
 void launch_prep_ncdhw_wino(const float* x, int B, Dims d, int C, SplitView wino, SplitEnc enc, hipStream_t st);
 int launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias,
-                     float out_scale, float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st);
+                     float out_scale, float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st, int out_cblk = 0);
 void launch_pack_weights_wino(const float* w, int cout, int cin, const int* h_seg_c, const int* h_seg_cp, int nseg,
                               const float* cin_scale, int B, float cout_scale, float wscale, _Float16* wpk,
                               hipStream_t st);
@@ -224,7 +230,7 @@ void launch_prep_wino43(const float* x, int B, Dims d, int C, const float* mean,
                         SplitEnc enc, hipStream_t st);
 void launch_prep_ncdhw_wino43(const float* x, int B, Dims d, int C, SplitView wino, SplitEnc enc, hipStream_t st);
 int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out,
-                       int B, Dims d, int cout, float* stats_ws, hipStream_t st);
+                       int B, Dims d, int cout, float* stats_ws, hipStream_t st, int out_cblk = 0);
 void launch_pack_weights_wino43(const float* w, int cout, int cin, const int* h_seg_c, const int* h_seg_cp, int nseg,
                                 const float* cin_scale, int B, float cout_scale, float wscale, _Float16* wpk, hipStream_t st);
 int64_t packed_weight_halves_wino43(int cout, int total_chunks);

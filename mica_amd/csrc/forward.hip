@@ -81,6 +81,7 @@ struct mica_ctx {
     StemPlan stem_plan{};
     float stem_wscale = 1.f;
     int stem_mode = 1;               // 0: the f32 VALU stem everywhere (A/B switch, MICA_STEM_MFMA=0)
+    int raw_cblk = 32;               // channel block of the raw tensors around the depthwise conv (0: plain NDHWC; A/B switch, MICA_RAW_CBLK=0)
     GateMLP exp_att;
     ConvLayer downsizing, feat_conv, fusion0;
     float *fg_w0 = nullptr, *fg_b0 = nullptr, *fg_w2 = nullptr, *fg_b2 = nullptr;
@@ -303,21 +304,22 @@ void prof_end(mica_ctx* c, int kind, double work, hipStream_t st) {
 // Launch a dense 3x3x3 conv (Winograd kernel).  With `mean`/`rstd` given the InstanceNorm statistics of the output are
 // produced too (fused into the kernel's epilogue, merged by stats_finalize).
 void run_conv(mica_ctx* c, ConvLayer& L, const SrcList& src, float* out, int B, hipStream_t st, float* mean = nullptr,
-              float* rstd = nullptr) {
+              float* rstd = nullptr, int out_cblk = 0) {
     const int pk = !L.f43 ? 2 : L.cout % 128 == 0 ? 5 : 6;       // F(2,3) kernel | F(4,3) kernel, 128-channel blocks | its tap-split 64-channel variant
     prof_begin(c, pk, st);
     const int P = L.f43 ? launch_conv_wino43(src.s, L.d_wpk, 0, L.d_b, 1.0f / (L.wscale * (c->ascale / WINO43_ASCALE_DIV)), out, B, c->d, L.cout,
-                                             mean ? c->ws : nullptr, st)
-                        : launch_conv_wino(src.s, L.d_wpk, 0, L.d_b, 1.0f / (L.wscale * c->ascale), out, B, c->d, L.cout, mean ? c->ws : nullptr, st);
+                                             mean ? c->ws : nullptr, st, out_cblk)
+                        : launch_conv_wino(src.s, L.d_wpk, 0, L.d_b, 1.0f / (L.wscale * c->ascale), out, B, c->d, L.cout, mean ? c->ws : nullptr, st,
+                                           out_cblk);
     prof_end(c, pk, L.flops_per_voxel * (double)c->V * B, st);
     if (mean) launch_stats_finalize(c->ws, B, P, L.cout, 1e-5f, mean, rstd, st);
 }
 
 Conv1Src split_src(const _Float16* p, int chunks_total, int off, int chunks) {
-    return Conv1Src{p, nullptr, nullptr, 0, chunks, chunks_total, off, 0};
+    return Conv1Src{p, nullptr, nullptr, 0, chunks, chunks_total, off, 0, 0};
 }
-Conv1Src raw_src(const float* p, int channels, const float* mean, const float* rstd, int relu) {
-    return Conv1Src{p, mean, rstd, 1, channels / 16, channels / 16, 0, relu};
+Conv1Src raw_src(const float* p, int channels, const float* mean, const float* rstd, int relu, int cblk = 0) {
+    return Conv1Src{p, mean, rstd, 1, channels / 16, channels / 16, 0, relu, cblk};
 }
 
 void make_operand(mica_ctx* c, const float* raw, int B, int C, const float* mean, const float* rstd, int relu, SplitView t3, SplitView t1,
@@ -412,8 +414,11 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_1, ch, 0, ch), none, nullptr, st, f43);
         run_conv(c, E.conv2, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch), c->R_a, B, st, c->v_mean, c->v_rstd);
         make_operand(c, c->R_a, B, C / 2, c->v_mean, c->v_rstd, 1, view(c->S_2, ch, 0, ch), none, nullptr, st, f43);
+        // conv3's raw output and the depthwise conv's live in the blocked raw layout [C / 32][V][32] (common.h): their readers - the
+        // depthwise conv, the 1x1 fusion - work on 32-channel slabs / chunk pairs, which are contiguous there
+        const int cb = c->raw_cblk;
         run_conv(c, E.conv3, SrcList().add(X, cc, 0, cc).add(c->S_1, ch, 0, ch).add(c->S_2, ch, 0, ch), c->R_b, B, st, c->v_mean3,
-                 c->v_rstd3);
+                 c->v_rstd3, cb);
         // x3 = relu(IN(conv3)) is never materialised: the depthwise conv and the 1x1 fusion normalise the raw tensor on load,
         // and its global average pool (the SE gate's input, model.py:256) is summed by the depthwise kernel as it loads.
         // The SE gate g (per tile and channel, > 0) scales the depthwise conv's INPUT (model.py:258, 99); the conv is linear, so
@@ -422,7 +427,7 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         // DualAttention (model.py:98-101): local branch
         {
             prof_begin(c, 1, st);
-            const int P = launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, nullptr, E.dw_w, E.dw_b, c->R_c, c->ws, c->ws_gap, st);
+            const int P = launch_depthwise(c->R_b, B, d, C, c->v_mean3, c->v_rstd3, nullptr, E.dw_w, E.dw_b, c->R_c, c->ws, c->ws_gap, st, cb);
             prof_end(c, 1, 8.0 * (double)C * V * B, st);     // algorithmic bytes: read + write 4 B per voxel and channel
             launch_finalize_sum(c->ws_gap, B, P, C, 1.0f / (float)V, c->v_pool, st);
             gate(c, E.se, c->v_pool, nullptr, B, nullptr, c->v_gse, nullptr, 0, st);      // SEBlock gate (model.py:254-258)
@@ -432,8 +437,8 @@ int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool 
         gate(c, E.ga, c->v_pool, c->v_gse, B, c->v_gse, nullptr, E.fusion.d_cin_scale + C, 2 * C, st);
         {
             // fusion (model.py:96, 101) reads the two branches raw: local = relu(IN(depthwise)), global = relu(IN(conv3)) * gates
-            const Conv1Src glob = raw_src(c->R_b, C, c->v_mean3, c->v_rstd3, 1);
-            run_conv1x1(c, E.fusion, raw_src(c->R_c, C, c->v_mean, c->v_rstd, 1), &glob, view(c->S_f, cc, 0, cc), c->R_a, B, st, E.transition.f43);
+            const Conv1Src glob = raw_src(c->R_b, C, c->v_mean3, c->v_rstd3, 1, cb);
+            run_conv1x1(c, E.fusion, raw_src(c->R_c, C, c->v_mean, c->v_rstd, 1, cb), &glob, view(c->S_f, cc, 0, cc), c->R_a, B, st, E.transition.f43);
         }
         // transition (model.py:141-147); c_e feeds the next encoder's 3^3 convs and the FPN's 1x1 lateral
         run_conv(c, E.transition, SrcList().add(c->S_f, cc, 0, cc), c->R_a, B, st, c->v_mean, c->v_rstd);
@@ -635,6 +640,7 @@ int mica_create_dims(int device, int max_batch, int td, int th, int tw, mica_ctx
     }
     mica_ctx* c = new mica_ctx();
     if (const char* ev = getenv("MICA_STEM_MFMA")) c->stem_mode = atoi(ev) != 0;
+    if (const char* ev = getenv("MICA_RAW_CBLK")) c->raw_cblk = atoi(ev) == 32 ? 32 : 0;
     if (const char* ev = getenv("MICA_F43")) { const int m = atoi(ev); c->f43_mode = m < 0 || m > 3 ? 3 : m; }      // A/B switch (0: the F(2,3) kernel everywhere)
     c->device = device;
     c->maxB = max_batch;

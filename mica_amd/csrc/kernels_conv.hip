@@ -143,7 +143,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                                                              const float* __restrict__ bias, float out_scale,
                                                              float* __restrict__ out, Dims d, int cout, int total_chunks,
                                                              int ntx, int nty, int nnb, int items_per_b, int total_items,
-                                                             float* __restrict__ stats_ws) {
+                                                             float* __restrict__ stats_ws, int ocb) {
+    // ocb: channel block of the OUTPUT layout (common.h: raw tensors): cout for plain NDHWC [V][cout], else [cout / ocb][V][ocb]
     using G = GeoW;
     static_assert(BN == 128 || BN == 64 || BN == 32, "three variants");
     // BN = 128: the two wave groups (wn) own 64 output channels each and walk all 14 steps of a chunk.
@@ -487,9 +488,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                         }
                         const bool in = gy < d.H && gz < d.D && gx < d.W, odd = in && gx + 1 < d.W;
                         if (in) {
-                            float* o = out + ((int64_t)ib * V + (int64_t)(gz * d.H + gy) * d.W + gx) * cout + n0;
+                            // (blocks are 32 channels: shifts instead of a per-lane division in a kernel that has no registers to spare)
+                            float* o = out + (int64_t)ib * V * cout + (BN != 32 && ocb != cout ? (int64_t)(n0 >> 5) * V * 32 + (n0 & 31) : (int64_t)n0) +
+                                       ((int64_t)(gz * d.H + gy) * d.W + gx) * (BN != 32 ? ocb : cout);
                             *reinterpret_cast<float4*>(o) = make_float4(ve[0], ve[1], ve[2], ve[3]);
-                            if (odd) *reinterpret_cast<float4*>(o + cout) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+                            if (odd) *reinterpret_cast<float4*>(o + (BN != 32 ? ocb : cout)) = make_float4(vo[0], vo[1], vo[2], vo[3]);
                         }
                         const float we = in ? 1.f : 0.f, wo = odd ? 1.f : 0.f;
                         sn += we + wo;
@@ -565,10 +568,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 static int wino16_block(int cout) { return cout % 128 == 0 ? 128 : cout % 64 == 0 ? 64 : 32; }
 
 static int launch_conv_wino16(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
-                              float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
+                              float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st, int out_cblk) {
     int total = 0;
     for (int i = 0; i < s.n; ++i) total += s.chunks[i];
     const int bn = wino16_block(cout);
+    // the blocked raw layout has 32-channel blocks; only conv3 layers write it (Cout = 64, 128: never the 32-channel variant)
+    const int ocb = out_cblk == 32 && cout % 32 == 0 && bn != 32 ? 32 : cout;
+    if (out_cblk != 0 && ocb == cout) { refuse_launch("conv_wino16: blocked output needs Cout a multiple of 64"); return 0; }
     int ntx = (d.W + 15) / 16, nty = (d.H + 3) / 4, ntz = (d.D + 3) / 4, nnb = cout / bn;
     size_t lds = 2 * GeoW::CH_BYTES;
     static PerDeviceOnce once;
@@ -589,21 +595,21 @@ static int launch_conv_wino16(const ConvSrcs& s, const _Float16* wpk, int64_t wp
     const int nwg = total_items >= cus ? cus : ((total_items + 7) / 8) * 8;
     if (bn == 128)
         hipLaunchKernelGGL((conv_wino16_kernel<128>), dim3(nwg), dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
-                           cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws);
+                           cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws, ocb);
     else if (bn == 64)
         hipLaunchKernelGGL((conv_wino16_kernel<64>), dim3(nwg), dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
-                           cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws);
+                           cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws, ocb);
     else
         hipLaunchKernelGGL((conv_wino16_kernel<32>), dim3(nwg), dim3(512), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d,
-                           cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws);
+                           cout, total, ntx, nty, nnb, items_per_b, total_items, stats_ws, ocb);
     return ntx * nty * ntz * 4;
 }
 
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null):
 // f32 [B][P][cout][3] = (count, mean, M2), to be merged by launch_stats_finalize.
 int launch_conv_wino(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale,
-                     float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
-    return launch_conv_wino16(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st);
+                     float* out, int B, Dims d, int cout, float* stats_ws, hipStream_t st, int out_cblk) {
+    return launch_conv_wino16(s, wpk, wpk_bstride, bias, out_scale, out, B, d, cout, stats_ws, st, out_cblk);
 }
 
 // weights for conv_wino16: [B][nb = Cout/bn][chunk][pair-step 5][p 4][unit 8][bn][8] halves (bn = 128 or 64); unit u: 0,1 = hi
@@ -761,7 +767,9 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ scale, const float* __restrict__ w27,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        float* __restrict__ stats_ws, float* __restrict__ gap_ws, int ntx, int nty) {
+                                                        float* __restrict__ stats_ws, float* __restrict__ gap_ws, int ntx, int nty, int vs) {
+    // vs: floats between consecutive voxels of a channel slab in x and out - C for plain NDHWC, the channel block (32) for the
+    // blocked raw layout [C / vs][V][vs] (common.h), in which a 32-channel slab is ONE contiguous run of memory
     extern __shared__ __attribute__((aligned(16))) float ring[];   // [3][LY][LX][16] ; reused for the statistics merge
     constexpr int DW_Y = DwGeo<YO, CQ>::Y, DW_LY = DwGeo<YO, CQ>::LY, DW_PLANE = DwGeo<YO, CQ>::PLANE, DW_C = 4 * CQ, NT = 64 * CQ;
     const int b = blockIdx.y;
@@ -805,14 +813,15 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
         const int v = e / CQ;
         const int lx = v % DW_LX, ly = v / DW_LX;
         const int cx = min(max(x0 + lx - 1, 0), d.W - 1), cy = min(max(y0 + ly - 1, 0), d.H - 1);
-        goff[k] = (cy * d.W + cx) * C + c0 + lq * 4;
+        goff[k] = (cy * d.W + cx) * vs + lq * 4;
         const bool val = e < DW_LX * DW_LY * CQ;
         if ((unsigned)(x0 + lx - 1) < (unsigned)d.W && (unsigned)(y0 + ly - 1) < (unsigned)d.H) okm |= 1u << k;
         if (val) valm |= 1u << k;
         if (val && lx >= 1 && lx <= DW_X && ly >= 1 && ly <= DW_Y) inm |= 1u << k;
     }
-    const float* xb = x + (int64_t)b * V * C;
-    const int64_t zstride = (int64_t)d.H * d.W * C;
+    const int64_t cbase = (int64_t)b * V * C + (int64_t)(c0 / vs) * V * vs + (c0 % vs);      // first channel of the slab, voxel 0
+    const float* xb = x + cbase;
+    const int64_t zstride = (int64_t)d.H * d.W * vs;
     auto fetch_plane = [&](int gz, float4 (&pre)[NE]) {
         const float* pz = xb + (int64_t)min(max(gz, 0), d.D - 1) * zstride;
 #pragma unroll
@@ -846,15 +855,16 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
 
     float sn = 0.f;
     float4 sk = make_float4(0, 0, 0, 0), s1 = sk, s2 = sk;
-    auto compute_plane = [&](int z) {
-        float4 acc[YO];
-#pragma unroll
-        for (int i = 0; i < YO; ++i) acc[i] = bv;
+    // The taps of output plane z in two parts: dz = 0 reads plane z - 1 (ring slot z % 3), dz = 1, 2 read planes z, z + 1.  Plane z + 2
+    // replaces plane z - 1 in its slot as soon as every wave is through the first part, and the normalise-and-store of that plane then runs
+    // beside the other two thirds of the taps instead of between two barriers of its own (round 5; the accumulation order is unchanged).
+    float4 acc[YO];
+    auto taps = [&](int z, int dz0, int dz1) {
 #ifdef MICA_DW_NOCOMPUTE
         if (z < 0)          // ablation: no taps (the outputs are the bias)
 #endif
 #pragma unroll 1
-        for (int dz = 0; dz < 3; ++dz) {
+        for (int dz = dz0; dz < dz1; ++dz) {
             const float* pl = ring + ((z + dz) % 3) * DW_PLANE + (xi * DW_C + cq * 4);
 #pragma unroll 1
             for (int dx = 0; dx < 3; ++dx) {
@@ -873,12 +883,28 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
                 }
             }
         }
+    };
+    auto first_part = [&](int z) {
+#pragma unroll
+        for (int i = 0; i < YO; ++i) acc[i] = bv;
+        taps(z, 0, 1);
+    };
+    auto second_part = [&](int z) {
+        taps(z, 1, 3);
         const int gx = x0 + xi;
 #pragma unroll
         for (int i = 0; i < YO; ++i) {
             const int gy = y0 + yq * YO + i;
             if (gx < d.W && gy < d.H) {
-                *reinterpret_cast<float4*>(out + ((int64_t)b * V + (int64_t)(z * d.H + gy) * d.W + gx) * C + c) = acc[i];
+#ifdef MICA_DW_NT
+                {
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    f4v v_; v_.x = acc[i].x; v_.y = acc[i].y; v_.z = acc[i].z; v_.w = acc[i].w;
+                    __builtin_nontemporal_store(v_, reinterpret_cast<f4v*>(out + cbase + ((int64_t)(z * d.H + gy) * d.W + gx) * vs + cq * 4));
+                }
+#else
+                *reinterpret_cast<float4*>(out + cbase + ((int64_t)(z * d.H + gy) * d.W + gx) * vs + cq * 4) = acc[i];
+#endif
                 if (sn == 0.f) sk = acc[i];
                 const float4 t = make_float4(acc[i].x - sk.x, acc[i].y - sk.y, acc[i].z - sk.z, acc[i].w - sk.w);
                 s1.x += t.x; s1.y += t.y; s1.z += t.z; s1.w += t.w;
@@ -905,23 +931,26 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
     // ring holds z-1, z, z+1
     for (int z = 0; z < d.D; z += 3) {
         DWCLK(0, fetch_plane(z + 4, preC));
-        DWCLK(1, compute_plane(z));
+        DWCLK(1, first_part(z));
         DWCLK(2, __syncthreads());                    // plane z-1 (slot z % 3) is no longer read by anyone
-        DWCLK(3, store_plane(z % 3, z + 2, preA));    // plane z+2 takes its place
-        DWCLK(4, __syncthreads());
+        DWCLK(3, store_plane(z % 3, z + 2, preA));    // plane z+2 takes its place ...
+        DWCLK(1, second_part(z));                     // ... while the taps on planes z, z+1 run
+        // ONE barrier per plane: plane z+2 is first read in the second part of output plane z+1, i.e. behind the next barrier, which no
+        // wave passes before every wave has finished this store; and the slot it overwrote was last read before the barrier above
         if (z + 1 >= d.D) break;
         DWCLK(0, fetch_plane(z + 5, preA));
-        DWCLK(1, compute_plane(z + 1));
+        DWCLK(1, first_part(z + 1));
         DWCLK(2, __syncthreads());
         DWCLK(3, store_plane((z + 1) % 3, z + 3, preB));
-        DWCLK(4, __syncthreads());
+        DWCLK(1, second_part(z + 1));
         if (z + 2 >= d.D) break;
         DWCLK(0, fetch_plane(z + 6, preB));
-        DWCLK(1, compute_plane(z + 2));
+        DWCLK(1, first_part(z + 2));
         DWCLK(2, __syncthreads());
         DWCLK(3, store_plane((z + 2) % 3, z + 4, preC));
-        DWCLK(4, __syncthreads());
+        DWCLK(1, second_part(z + 2));
     }
+    __syncthreads();                                  // the ring is reused below: every wave is through its last taps
 #ifdef MICA_DW_CLOCKS
     const long long t_done = __builtin_readcyclecounter();
 #endif
@@ -987,17 +1016,18 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null).
 template <int YO, int CQ>
 static void launch_depthwise_t(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, const float* scale,
-                               const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, int ntx, int nty, hipStream_t st) {
+                               const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, int ntx, int nty, int vs, hipStream_t st) {
     using Gm = DwGeo<YO, CQ>;
     const size_t lds = (3 * Gm::PLANE + 27 * Gm::DWC) * sizeof(float);
     static PerDeviceOnce once;
     once.run([&](int) { (void)hipFuncSetAttribute((const void*)depthwise_kernel<YO, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     dim3 grid((unsigned)(ntx * nty * (C / Gm::DWC)), B);
-    hipLaunchKernelGGL((depthwise_kernel<YO, CQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty);
+    hipLaunchKernelGGL((depthwise_kernel<YO, CQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, vs);
 }
 int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
-                     const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st) {
+                     const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st, int cblk) {
     const int ntx = (d.W + DW_X - 1) / DW_X;
+    const int vs = cblk > 0 && C % cblk == 0 && cblk % 32 == 0 ? cblk : C;      // a slab (16 or 32 channels) never straddles a block
     // The variant fixes the number and order of the statistics / pool partials of a tile, so it is chosen from the tile geometry
     // (C, H, W) alone - as if 8 tiles were in flight, the throughput case - never from the size of this call or the capacity of
     // the context: a tile's numbers do not depend on how many tiles share its call, nor on which engine computed them.
@@ -1005,15 +1035,15 @@ int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, co
     // 32-channel workgroups (full 128-B lines) when that still gives every CU at least two rounds of work
     if (C % 32 == 0 && (int64_t)ntx * ((d.H + 15) / 16) * (C / 32) * Bplan >= 256) {
         const int nty = (d.H + 15) / 16;
-        launch_depthwise_t<4, 8>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, st);
+        launch_depthwise_t<4, 8>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, vs, st);
         return ntx * nty;
     }
     // enough workgroups to fill 256 CUs twice: halve the column height when C * batch is small
     const bool small = (int64_t)ntx * ((d.H + 15) / 16) * (C / 16) * Bplan < 1024;
     const int Y = small ? 8 : 16;
     const int nty = (d.H + Y - 1) / Y;
-    if (small) launch_depthwise_t<2, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, st);
-    else launch_depthwise_t<4, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, st);
+    if (small) launch_depthwise_t<2, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, vs, st);
+    else launch_depthwise_t<4, 4>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, vs, st);
     return ntx * nty;
 }
 

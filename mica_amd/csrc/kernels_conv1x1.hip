@@ -104,7 +104,9 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
                 const int row = tid >> 1, kh = tid & 1;
                 const int v = v0 + row;
                 if (v < V) {
-                    const float* p = reinterpret_cast<const float*>(s.p) + ((int64_t)b * V + v) * (s.chunks_total * 16) + (s.chunk_off + w.lc) * 16 + kh * 8;
+                    // plain NDHWC [V][Cs], or the blocked raw layout [Cs / cblk][V][cblk] (a chunk pair = one 32-channel block)
+                    const int Cs = s.chunks_total * 16, cb = s.cblk > 0 ? s.cblk : Cs, ch = (s.chunk_off + w.lc) * 16 + kh * 8;
+                    const float* p = reinterpret_cast<const float*>(s.p) + (int64_t)b * V * Cs + (int64_t)(ch / cb) * V * cb + (int64_t)v * cb + ch % cb;
                     st[cc][0] = *reinterpret_cast<const float4*>(p);
                     st[cc][1] = *reinterpret_cast<const float4*>(p + 4);
                 }

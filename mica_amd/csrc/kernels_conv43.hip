@@ -124,7 +124,8 @@ template <int BN_>
 __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Float16* __restrict__ wpk, int64_t wpk_bstride,
                                                           const float* __restrict__ bias, float out_scale, float* __restrict__ out,
                                                           Dims d, int cout, int total_chunks, int ntx, int nty, int nnb,
-                                                          int items_per_b, int total_items, float* __restrict__ stats_ws) {
+                                                          int items_per_b, int total_items, float* __restrict__ stats_ws, int ocb) {
+    // ocb: channel block of the OUTPUT layout: cout for plain NDHWC, else [cout / ocb][V][ocb] (common.h: raw tensors)
     using G = Geo43;
     constexpr int BN = BN_, NCT = 4, NF = 4;
     constexpr bool SPLIT = BN == 64;                         // the two wave groups split the taps instead of the channels
@@ -523,7 +524,8 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                     for (int j = 0; j < 4; ++j) {
                         const bool in = inr && gx + j < d.W;
                         if (in) {
-                            float* o = out + ((int64_t)ib * V + (int64_t)(gz * d.H + gy) * d.W + gx + j) * cout + n0;
+                            float* o = out + (int64_t)ib * V * cout + (ocb != cout ? (int64_t)(n0 >> 5) * V * 32 + (n0 & 31) : (int64_t)n0) +
+                                       ((int64_t)(gz * d.H + gy) * d.W + gx + j) * ocb;
                             *reinterpret_cast<float4*>(o) = make_float4(yv[j][0], yv[j][1], yv[j][2], yv[j][3]);
                         }
                         const float wv = in ? 1.f : 0.f;
@@ -616,7 +618,8 @@ extern "C" int mica_debug_conv43(unsigned* h_out, int n) {
 
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null): f32 [B][P][cout][3].
 int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstride, const float* bias, float out_scale, float* out,
-                       int B, Dims d, int cout, float* stats_ws, hipStream_t st) {
+                       int B, Dims d, int cout, float* stats_ws, hipStream_t st, int out_cblk) {
+    const int ocb = out_cblk == 32 && cout % 32 == 0 ? 32 : cout;          // the blocked raw layout has 32-channel blocks
     if (!conv_wino43_eligible(cout)) { refuse_launch("conv_wino43: cout must be a multiple of 128, or 64"); return 0; }
     if ((int64_t)d.D * d.H * ((d.W + 3) / 4) * 24 * 16 >= (1ll << 31)) { refuse_launch("conv_wino43: tile too large for 32-bit slab offsets"); return 0; }
     int total = 0;
@@ -644,10 +647,10 @@ int launch_conv_wino43(const ConvSrcs& s, const _Float16* wpk, int64_t wpk_bstri
     const int nwg = total_items >= cus ? cus : ((total_items + 7) / 8) * 8;
     if (bn == 128)
         hipLaunchKernelGGL(conv_wino43_kernel<128>, dim3(nwg), dim3(768), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout, total, ntx,
-                           nty, nnb, items_per_b, total_items, stats_ws);
+                           nty, nnb, items_per_b, total_items, stats_ws, ocb);
     else
         hipLaunchKernelGGL(conv_wino43_kernel<64>, dim3(nwg), dim3(768), lds, st, s, wpk, wpk_bstride, bias, out_scale, out, d, cout, total, ntx,
-                           nty, nnb, items_per_b, total_items, stats_ws);
+                           nty, nnb, items_per_b, total_items, stats_ws, ocb);
     return ntx * nty * ntz * 4;
 }
 
