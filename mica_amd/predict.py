@@ -247,6 +247,9 @@ class CryoEMPredictor:
         try:
             from .pipeline import VolumePredictor
             m, a = self.resident
+            for ent in self.resident:            # the tile-file writers held back for the tiler's and the weight load's sake: go
+                if ent is not None and ent.writer is not None:
+                    ent.writer.release()
             af = a.volume if a is not None and len(a.channels) == 24 else None
             vols = VolumePredictor(self.engine, m.grid_size, m.padding, self.engine.max_batch).predict_volume(m.volume, af, to_host=True)
             self.timing_stats['inference'] = time.time() - t0

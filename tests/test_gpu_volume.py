@@ -659,3 +659,68 @@ def test_the_disk_free_snippet_printed_in_integration_md_runs_as_printed(tmp_pat
     assert float(vols["backbone_probability"].min()) >= 0.0 and float(vols["backbone_probability"].max()) <= 1.0
     assert np.array_equal(np.unique(me.AAPred), np.unique(me.AAPred).round()) and me.AAPred.min() >= 0 and me.AAPred.max() <= 19
     ns["eng"].close()
+
+
+def test_handoff_modes_no_files_sync_files_and_foreign_encodings(tmp_path, weights):
+    """mica_amd/handoff.py behind the reference's call sites (utils/modeler.py:684-706, 724-738): `GridCreator(write_files=False)` leaves
+    no tile file and the predictor of this process still returns the volumes; `write_files="sync"` has every file on disk when the
+    wrapper returns; a predictor told to read the files agrees bit for bit; and when the encodings' tile files under grids_path were
+    written by somebody else (no resident volume for them), the predictor reads files instead of mixing the two sources."""
+    from mica_amd import handoff, mrc
+    from mica_amd.af3_encoding import CHANNEL_NAMES
+    from mica_amd.create_grids import GridCreator
+    from mica_amd.predict import CryoEMPredictor
+    handoff.clear()
+    shape = (60, 40, 40)                                                   # (x, y, z) after the tiler's transpose: two tiles
+    vol = synth_density(shape, 41)
+    af = np.zeros((24, *shape), np.float32)
+    af[:, 50:60, 10:30, 10:30] = synth_af((10, 20, 20), 3, 0.05)           # only the second tile's central region sees atoms
+    inp = tmp_path / "in"
+    os.makedirs(inp / "AF3_encodings")
+    mp = str(inp / "resampled_normalized_map.mrc")
+    mrc.write_mrc(mp, np.ascontiguousarray(vol.transpose(2, 1, 0)))
+    for c, name in enumerate(CHANNEL_NAMES):
+        mrc.write_mrc(str(inp / "AF3_encodings" / f"{name}_encoding.mrc"), np.ascontiguousarray(af[c].transpose(2, 1, 0)))
+    ck = str(tmp_path / "ckpt.pth")
+    torch.save({"epoch": 0, "model_state_dict": {"module." + k: torch.from_numpy(v.copy()) for k, v in weights.items()}}, ck)
+
+    def chain(tag, write_files, resident):
+        grids = str(tmp_path / tag)
+        gc = GridCreator(quiet=True, write_files=write_files)
+        r1 = gc.create_normalized_map_grids(mp, os.path.join(grids, "normalized_map_grids"))
+        r2 = gc.create_AF3_encodings_grids(str(inp / "AF3_encodings"), os.path.join(grids, "AF3_encoding_grids"))
+        assert r1["success"] and r1["grid_count"] == 2 and r2["success"] and r2["total_grids"] == 48
+        files_now = len(glob.glob(os.path.join(grids, "*", "*.npz"))) + len(glob.glob(os.path.join(grids, "*", "*", "*.npz")))
+        pred = CryoEMPredictor(ck, grids + "/", str(tmp_path / "out"), save_output=False, device="cuda", quiet=True)
+        pred.use_resident_volumes = resident
+        ok, vols = pred.run_prediction()
+        assert ok and (pred.resident is not None) == resident
+        files_after = len(glob.glob(os.path.join(grids, "*", "*.npz"))) + len(glob.glob(os.path.join(grids, "*", "*", "*.npz")))
+        return vols, files_now, files_after, grids
+
+    v_none, n0, n1, _ = chain("nofiles", False, True)
+    assert n0 == 0 and n1 == 0
+    v_sync, n0, n1, g_sync = chain("sync", "sync", False)
+    assert n0 == 50 and n1 == 50                                           # all there when the wrapper returned
+    v_bg, n0, n1, _ = chain("background", True, True)
+    assert n1 == 50                                                        # the predictor returns after the background writer is done
+    for k in v_none:
+        assert np.array_equal(v_none[k], v_sync[k]) and np.array_equal(v_none[k], v_bg[k]), k
+    assert float(np.abs(v_none["backbone_probability"][:48] - v_none["backbone_probability"][48:58].mean()).max()) > 0     # not a constant volume
+    # foreign encodings: the map is resident, the encodings' tile files come from elsewhere -> the files are read for both
+    grids = str(tmp_path / "foreign")
+    gc = GridCreator(quiet=True, write_files=False)
+    assert gc.create_normalized_map_grids(mp, os.path.join(grids, "normalized_map_grids"))["success"]
+    import shutil
+    shutil.copytree(os.path.join(g_sync, "AF3_encoding_grids"), os.path.join(grids, "AF3_encoding_grids"))
+    pred = CryoEMPredictor(ck, grids + "/", str(tmp_path / "out"), save_output=False, device="cuda", quiet=True)
+    ok, vols = pred.run_prediction()
+    assert pred.resident is None and (ok, vols) == (False, {})              # no map tile FILES exist (write_files=False): loud failure, nothing mixed
+    gc2 = GridCreator(quiet=True, write_files="sync")
+    assert gc2.create_normalized_map_grids(mp, os.path.join(grids, "normalized_map_grids"))["success"]
+    pred = CryoEMPredictor(ck, grids + "/", str(tmp_path / "out"), save_output=False, device="cuda", quiet=True)
+    ok, vols = pred.run_prediction()
+    assert ok and pred.resident is None
+    for k in v_none:
+        assert np.array_equal(v_none[k], vols[k]), k
+    handoff.clear()
