@@ -52,7 +52,7 @@ try:
         t2 = time.perf_counter()
         assert ok and (pred.resident is not None) == resident
         T = r1["grid_count"]
-        nfiles = sum(len(fs) for _, _, fs in os.walk(grids))
+        nfiles = sum(len([f for f in fs if f.endswith('.npz')]) for _, _, fs in os.walk(grids))
         shutil.rmtree(grids)
         t3 = time.perf_counter()
         print(f"{tag}: tiling {t1 - t0:.2f} s + prediction {t2 - t1:.2f} s (model load {pred.timing_stats['model_loading']:.2f}, inference "
