@@ -71,10 +71,13 @@ class SlabDownloader:
                         self.error = ex
                     finally:
                         self.free[k].set()
-        self._alloc = threading.Thread(target=alloc, name="mica-pinned-alloc")
+        # daemon threads: a caller that fails half way through a map (and never reaches finish()) must not leave a thread behind that
+        # keeps the interpreter from exiting; close() ends them in the orderly case
+        self._alloc = threading.Thread(target=alloc, name="mica-pinned-alloc", daemon=True)
         self._alloc.start()
-        self._unpack = threading.Thread(target=unpack, name="mica-slab-unpack")
+        self._unpack = threading.Thread(target=unpack, name="mica-slab-unpack", daemon=True)
         self._unpack.start()
+        self._closed = False
 
     def _download(self, s: int):
         k = s & 1
@@ -100,11 +103,20 @@ class SlabDownloader:
             self._download(self.next)
             self.next += 1
 
+    def close(self):
+        """End the helper threads (idempotent); what is still queued is unpacked first."""
+        if not self._closed:
+            self._closed = True
+            self.jobs.put(None)
+            self._unpack.join()
+            self._alloc.join()
+
     def finish(self):
         """-> the host array [23, N0, N1, N2] (numpy), complete."""
-        self.tiles_done(self.per * self.nslabs)
-        self.jobs.put(None)
-        self._unpack.join()
+        try:
+            self.tiles_done(self.per * self.nslabs)
+        finally:
+            self.close()
         if self.error is not None:
             raise self.error
         return self.host
@@ -143,15 +155,19 @@ class VolumePredictor:
         T = int(e.lib.mica_tile_count(n0, n1, n2, self.grid))
         out = torch.zeros((23, n0, n1, n2), dtype=torch.float32, device=e.device)
         dl = SlabDownloader(out, self.grid, (-(-n1 // self.grid)) * (-(-n2 // self.grid))) if to_host else None
-        for first in range(0, T, self.batch):
-            count = min(self.batch, T - first)
-            rec = self.run_batch(vol, af_vol, first, count)
-            e.stitch_tiles(rec, out, self.grid, self.pad, first)
+        try:
+            for first in range(0, T, self.batch):
+                count = min(self.batch, T - first)
+                rec = self.run_batch(vol, af_vol, first, count)
+                e.stitch_tiles(rec, out, self.grid, self.pad, first)
+                if dl is not None:
+                    dl.tiles_done(first + count)
             if dl is not None:
-                dl.tiles_done(first + count)
-        if dl is not None:
-            return volume_dict(dl.finish())
-        return volume_dict(out)
+                return volume_dict(dl.finish())
+            return volume_dict(out)
+        finally:
+            if dl is not None:
+                dl.close()
 
     def predict_maps_streamed(self, maps, afs=None):
         """Several independent maps back to back (BASELINE.json configs[4]) with host buffers on both sides.
@@ -270,10 +286,14 @@ class VolumePredictor:
                 done[0] = max(done[0], first + int(rec.shape[0]))
                 dl.tiles_done(done[0])
 
-        sharded_records(run, stitch, T, self.batch, (23, g, g, g), e.device, group=group, stitch_rank=0,
-                        force_collective=force_collective, stats=stats, gather_to_root=gather_to_root)
-        if rank != 0:
-            return None
-        if dl is not None:
-            return volume_dict(dl.finish())
-        return volume_dict(out)
+        try:
+            sharded_records(run, stitch, T, self.batch, (23, g, g, g), e.device, group=group, stitch_rank=0,
+                            force_collective=force_collective, stats=stats, gather_to_root=gather_to_root)
+            if rank != 0:
+                return None
+            if dl is not None:
+                return volume_dict(dl.finish())
+            return volume_dict(out)
+        finally:
+            if dl is not None:
+                dl.close()

@@ -237,6 +237,9 @@ class CryoEMPredictor:
             self.logger.error(f"Inference failed: {e}")
             self.timing_stats['inference'] = time.time() - t0
             return None
+        finally:
+            if 'dl' in locals():
+                dl.close()
 
     def run_inference_resident(self):
         """The hot loop on the volumes GridCreator left on the GPU: gather -> forward -> softmax / argmax -> stitch per batch of

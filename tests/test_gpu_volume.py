@@ -724,3 +724,24 @@ def test_handoff_modes_no_files_sync_files_and_foreign_encodings(tmp_path, weigh
     for k in v_none:
         assert np.array_equal(v_none[k], vols[k]), k
     handoff.clear()
+
+
+def test_a_failing_map_leaves_no_helper_thread_behind(weights):
+    """`predict_volume(to_host=True)` runs helper threads (pinned staging allocation, slab unpack).  A forward that fails half way through
+    the map - here a non-finite tile, which the library refuses with MICA_ERR_RANGE - must end them: a left-over thread waiting on its
+    queue would keep the interpreter from exiting."""
+    import threading
+    from mica_amd.engine import Engine, MicaHipError
+    from mica_amd.pipeline import VolumePredictor
+    e = Engine(0, max_batch=2, tile_size=64)
+    e.load_state_dict(weights)
+    vol = torch.from_numpy(synth_density((100, 60, 50), 5)).cuda()
+    vol[90, 30, 30] = float("nan")                           # inside the last x slab: the first slabs are already on their way to the host
+    with pytest.raises(MicaHipError):
+        VolumePredictor(e, 48, 8, 2).predict_volume(vol, None, to_host=True)
+    names = [t.name for t in threading.enumerate() if t.is_alive()]
+    assert not any(n.startswith(("mica-slab", "mica-pinned")) for n in names), names
+    vol[90, 30, 30] = 0.5
+    out = VolumePredictor(e, 48, 8, 2).predict_volume(vol, None, to_host=True)      # and the engine still works
+    assert isinstance(out["backbone_probability"], np.ndarray) and np.isfinite(out["amino_acid_probability"]).all()
+    e.close()
