@@ -501,3 +501,24 @@ def test_bench_refuses_counter_figures_of_other_sources(tmp_path, monkeypatch):
     assert t == {} and "REFUSED" in note
     sq, note = bench.load_sq_summary("0" * 16, True)
     assert sq == {} and "REFUSED" in note
+
+
+def test_committed_counter_profiles_belong_to_these_library_sources():
+    """The newest profiles/rNN_pmc_traffic.json / rNN_pmc_sq_summary.txt - what bench.py quotes `roofline.traffic`, `mfma_busy` and
+    `held_clock_ghz` from - were collected on exactly the library sources in this tree (a kernel change without a re-profile makes
+    bench.py report null for them: this test is the reminder to run tools/profile.sh again), and the committed bench line's hardware
+    fraction agrees with the counters' MFMA-busy x held clock / 2.4 GHz within 5 %."""
+    import bench
+    from mica_amd._cabi import source_hash
+    h = source_hash()
+    t, tnote = bench.load_traffic(h, True)
+    sq, sqnote = bench.load_sq_summary(h, True)
+    assert t and "REFUSED" not in tnote, tnote
+    assert sq and "REFUSED" not in sqnote, sqnote
+    assert t["conv_wino43_kernel<128>"]["hbm_bytes"] > 1e9 and sq["conv_wino43_kernel<128>"]["mfma_busy"] > 0.3
+    line = json.load(open(os.path.join(ROOT, "profiles", bench._newest("r[0-9][0-9]_pmc_traffic.json")[-20:-17] + "_bench_default.json")))
+    r = line["roofline"]
+    assert r["profile_source"]["library_source_hash"] == h
+    assert 0.0 < r["frac"] <= 1.0 and r["peak"] == 2500.0 and r["traffic"] is not None
+    assert abs(r["frac"] - r["mfma_busy_x_clock_over_2p4"]) / r["frac"] < 0.05
+    assert line["sustained"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
