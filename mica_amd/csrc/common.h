@@ -59,6 +59,17 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // The range test is one v_med3 + one compare into a scalar mask per value; which kind of violation it was is worked out on a
 // wave-uniform slow path that only runs when some lane saw one (the per-value flag logic used to be a third of the encoder's
 // VALU work, and the 1x1 kernels are VALU-bound on exactly this).
+// development (power experiment, tools/exp/lomask.sh): -DMICA_EXP_LOMASK=n clears the n low mantissa bits of every lo half (activations
+// here, weights in the packers): do the matrix cores draw less power - and so hold a higher clock - when the operands toggle fewer bits?
+__device__ __forceinline__ _Float16 mica_lo_half(float r) {
+    _Float16 l = (_Float16)r;
+#ifdef MICA_EXP_LOMASK
+    unsigned short b = __builtin_bit_cast(unsigned short, l);
+    b &= (unsigned short)(0xFFFFu << MICA_EXP_LOMASK);
+    l = __builtin_bit_cast(_Float16, b);
+#endif
+    return l;
+}
 __device__ __forceinline__ void mica_split8(const float (&y)[8], half8& hi, half8& lo, int& bad, float ascale) {
     float c[8];
     unsigned long long viol = 0;
@@ -77,7 +88,7 @@ __device__ __forceinline__ void mica_split8(const float (&y)[8], half8& hi, half
     for (int j = 0; j < 8; ++j) {
         const _Float16 h = (_Float16)c[j];
         hi[j] = h;
-        lo[j] = (_Float16)(c[j] - (float)h);
+        lo[j] = mica_lo_half(c[j] - (float)h);
     }
 }
 // Winograd F(4,3) along x with the interpolation points {0, +-3/2, +-2/3, inf} (kernels_conv43.hip): input transform of one

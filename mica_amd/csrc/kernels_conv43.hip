@@ -705,7 +705,7 @@ __global__ void pack_weights_wino43_kernel(const float* __restrict__ w, int cout
             if (cin_scale) v *= cin_scale[(int64_t)b * cin + ci];
         }
         _Float16 hi = (_Float16)v;
-        _Float16 lo = (_Float16)(v - (float)hi);
+        _Float16 lo = mica_lo_half(v - (float)hi);
         o[j] = kind ? lo : hi;
     }
     *reinterpret_cast<half8*>(wpk + (int64_t)b * per_b + e * 8) = o;
