@@ -66,9 +66,13 @@ class CryoEMPredictor:
         m = handoff.lookup_grids(os.path.join(self.grids_path, "normalized_map_grids"))
         if m is None or m.kind != "map":
             return None
+        dev = torch.device(self.device if ":" in str(self.device) else "cuda:0")
+        if m.volume.device != dev:
+            return None                      # the volumes live on another GPU than the one this predictor was given: read the files
         afdir = os.path.join(self.grids_path, "AF3_encoding_grids")
         a = handoff.lookup_grids(afdir)
-        if a is not None and (a.kind != "af3" or a.shape != m.shape or (a.grid_size, a.padding) != (m.grid_size, m.padding)):
+        if a is not None and (a.kind != "af3" or a.shape != m.shape or (a.grid_size, a.padding) != (m.grid_size, m.padding) or
+                              a.volume.device != dev):
             a = None
         if a is None and os.path.isdir(afdir) and glob.glob(os.path.join(afdir, "*_grids", "*.npz")):
             return None                      # encodings tiled by somebody else: their files are the only copy
