@@ -75,7 +75,7 @@ int mica_load_weight(mica_ctx* ctx, const char* name, const float* h_data, const
  * - f16 hi + lo halves of w * 2^k (k per layer: max |w| in (2048, 4096]):
  *     1x1x1 convs                 [Cin/16][hi|lo][k-half][Cout][8]
  *     3x3x3 convs, F(2,3) kernel  [Cout/bn][Cin/16][tap pair 5][Winograd position 4][unit 8][bn][8], bn = 128 / 64 / 32
- *     3x3x3 convs, F(4,3) kernel  [Cout/128][Cin/16][tap pair 5][Winograd position 6][unit 8][128][8]   (see
+ *     3x3x3 convs, F(4,3) kernel  [Cout/bn][Cin/16][tap pair 5][Winograd position 6][unit 8][bn][8], bn = 128 (64 for Cout = 64)   (see
  *                                 mica_set_conv_variant); units = hi / lo x first / second tap of the pair x channel half
  *   with the Winograd weight transforms applied (the layers whose inputs carry a per-tile gate are re-packed per tile at run time).
  * Blocks until done.                                                                                                            */

@@ -65,6 +65,59 @@ try:
     T = chain("hand-off, tile files written in the background (default)", True)
     chain("hand-off, no tile files (write_files=False)", False)
     chain("predictor reads the tile files (cold path), 4 reader threads", "sync", resident=False)
+    # ---- the whole of getData + nnPred (utils/modeler.py:673-738): DataPreprocessor in front, from the raw map and a docked model ----
+    from mica_amd.preprocessing import DataPreprocessor
+    raw = ((vol - np.float32(0.3)) * np.float32(3.0)).astype(np.float32)
+    inp = os.path.join(tmp, "input", "9999")
+    os.makedirs(os.path.join(inp, "AF3_results"))
+    raw_path = os.path.join(inp, "emd_9999.mrc")
+    mrc.write_mrc(raw_path, raw)
+    rng = np.random.default_rng(5)
+    aas = ['ALA', 'CYS', 'ASP', 'GLU', 'PHE', 'GLY', 'HIS', 'ILE', 'LYS', 'LEU', 'MET', 'ASN', 'PRO', 'GLN', 'ARG', 'SER', 'THR', 'VAL', 'TRP', 'TYR']
+    lines = []
+    nres = max(200, n * n * n // 8000)                                     # about one residue per 20^3 voxels
+    for r in range(nres):
+        c0 = rng.random(3) * (n - 8) + 3
+        for a in ("N", "CA", "C", "O", "CB"):
+            x, y, z = c0 + rng.random(3) * 2.0
+            nm = " " + a.ljust(3)
+            lines.append("%-6s%5d %4s%1s%3s %1s%4d    %8.3f%8.3f%8.3f%6.2f%6.2f          %2s\n" % ("ATOM", (len(lines) + 1) % 100000, nm, " ", aas[r % 20], "A", (r + 1) % 10000, x, y, z, 1.0, 20.0, a[0]))
+    pdb = os.path.join(inp, "9999_af3_docked.pdb")
+    open(pdb, "w").write("".join(lines) + "END\n")
+
+    def full_chain(tag, dp_mode, write_files):
+        shutil.rmtree(grids, ignore_errors=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dp = DataPreprocessor(map_path=raw_path, AF3_results=os.path.join(inp, "AF3_results"), quiet=True, engine=eng, write_files=dp_mode)
+        dp.resample_and_normalize_map()
+        t1 = time.perf_counter()
+        assert dp.create_AF3_encodings(pdb) is True
+        t2 = time.perf_counter()
+        gc = GridCreator(quiet=True, engine=eng, write_files=write_files)
+        r1 = gc.create_normalized_map_grids(normalized_map_path=dp.normalized_map_path, output_dir=os.path.join(grids, "normalized_map_grids"))
+        r2 = gc.create_AF3_encodings_grids(AF3_encodings_path=os.path.join(inp, "AF3_encodings"), output_dir=os.path.join(grids, "AF3_encoding_grids"))
+        assert r1["success"] and r2["success"]
+        t3 = time.perf_counter()
+        pred = CryoEMPredictor(model_path=ck, grids_path=grids + "/", output_path=os.path.join(tmp, "out"), save_output=False, device="cuda", quiet=True)
+        ok, vols = pred.run_prediction()
+        t4 = time.perf_counter()
+        assert ok and pred.resident is not None
+        shutil.rmtree(grids)
+        os.remove(dp.normalized_map_path)
+        shutil.rmtree(os.path.join(inp, "AF3_encodings"))                 # what utils/modeler.py:755-757 does
+        T = r1["grid_count"]
+        print(f"{tag}: resample+normalise {t1 - t0:.2f} s + AF3 encodings ({nres * 5} atoms) {t2 - t1:.2f} s + tiling {t3 - t2:.2f} s + prediction {t4 - t3:.2f} s "
+              f"= {t4 - t0:.2f} s -> {T / (t4 - t0):.1f} sub-grids/s for ALL of getData + nnPred ({T} tiles)", flush=True)
+        return vols
+
+    full_chain("getData + nnPred, warm-up", "sync", True)
+    va = full_chain("getData + nnPred, defaults (MRC files complete when each call returns, tile files in the background)", "sync", True)
+    vb = full_chain("getData + nnPred, every file written behind the calls (DataPreprocessor write_files='background')", "background", True)
+    vc = full_chain("getData + nnPred, no tile files, MRC files in the background", "background", False)
+    for k in va:
+        assert np.array_equal(va[k], vb[k]) and np.array_equal(va[k], vc[k]), k
+    print("the three full chains agree bit for bit")
     vp = VolumePredictor(Engine(0, max_batch=8, tile_size=64), 48, 8, 8)
     vp.e.load_state_dict(w)
     dv, da = torch.from_numpy(np.ascontiguousarray(vol.transpose(2, 1, 0))).cuda(), torch.from_numpy(np.ascontiguousarray(af.transpose(0, 3, 2, 1))).cuda()
