@@ -4,6 +4,8 @@ PyTorch is used for device memory and streams only (tensor.data_ptr() is what cr
 from __future__ import annotations
 
 import ctypes as C
+import functools
+import threading
 
 import numpy as np
 import torch
@@ -37,6 +39,7 @@ class Engine:
             raise MicaHipError(f"device {device!r} is not a GPU; mica_amd has no CPU path")
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         self.lib = _cabi.load_library()
+        self.call_lock = threading.RLock()        # see _serialise_engine_methods below
         self.max_batch = int(max_batch)
         self.tile_shape = tuple(int(v) for v in tile_size) if isinstance(tile_size, (tuple, list)) else (int(tile_size),) * 3
         if len(self.tile_shape) != 3:
@@ -446,3 +449,23 @@ class Engine:
         ms, n, wk = C.c_double(), C.c_int64(), C.c_double()
         self._check(self.lib.mica_get_profile(self._h, kind, C.byref(ms), C.byref(n), C.byref(wk)), "mica_get_profile")
         return ms.value, n.value, wk.value
+
+
+def _serialise_engine_methods():
+    """Every public method of an Engine runs under that engine's lock: a context is not thread-safe (include/mica_hip.h), ctypes
+    releases the GIL for the duration of a call, and an engine may be shared between the caller's thread and a background one (the
+    tile-file writer of mica_amd/handoff.py gathers with the tiler's engine).  The lock spans the call AND the reading of its error
+    text / result registers, so one thread's failure is never reported with another's message."""
+    def serial(fn):
+        @functools.wraps(fn)
+        def method(self, *a, **k):
+            with self.call_lock:
+                return fn(self, *a, **k)
+        return method
+
+    for name, member in list(vars(Engine).items()):
+        if callable(member) and not name.startswith("_"):
+            setattr(Engine, name, serial(member))
+
+
+_serialise_engine_methods()

@@ -90,11 +90,12 @@ _FILE_POOL = None
 
 
 def _file_pool():
-    """A few threads for whole-volume files (an MRC writer holds a float64 copy of its volume for the header statistics)."""
+    """A few threads for whole-volume files (an MRC writer holds a float32 copy of its volume, and a float64 one for the header
+    statistics when the caller has none).  MICA_FILE_WRITERS overrides the count."""
     global _FILE_POOL
     with _LOCK:
         if _FILE_POOL is None:
-            _FILE_POOL = ThreadPoolExecutor(max_workers=3, thread_name_prefix="mica-file-writer")
+            _FILE_POOL = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("MICA_FILE_WRITERS", "3"))), thread_name_prefix="mica-file-writer")
         return _FILE_POOL
 
 
@@ -438,8 +439,8 @@ class TileFileWriter:
                     for f in inflight[b]:
                         f.result()               # the jobs that read this pinned buffer two chunks ago
                     count = min(self.chunk, T - first)
-                    # "a ctx is not thread-safe" (include/mica_hip.h): writers that share an engine take turns for the call itself
-                    with torch.cuda.stream(stream), e.__dict__.setdefault("_call_lock", threading.Lock()):
+                    # "a ctx is not thread-safe" (include/mica_hip.h): every Engine method runs under the engine's own lock (engine.py)
+                    with torch.cuda.stream(stream):
                         e.gather_tiles(self.volume, self.grid, self.pad, first, count, out=devs[b][:count])
                         pins[b][:count].copy_(devs[b][:count], non_blocking=True)
                     stream.synchronize()

@@ -128,6 +128,14 @@ class DataPreprocessor:
             hdn = mrc.MrcHeader(nx=nx, ny=ny, nz=nz, mode=2, nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart, mx=nx, my=ny, mz=nz,
                                 cella=(float(nx), float(ny), float(nz)), mapc=hd.mapc, mapr=hd.mapr, maps=hd.maps,
                                 origin=tuple(float(np.float32(v)) for v in hd.origin))
+            # header statistics of a 0/1 volume from one count per channel: min / max / mean are exactly numpy's float64 results
+            # (an integer sum), the standard deviation sqrt(p (1 - p)) equals numpy's two-pass value after the header's float32 rounding
+            ones = u8.sum(dim=(1, 2, 3), dtype=torch.int64).cpu().tolist()
+            nvox = float(nz * ny * nx)
+
+            def stats01(k):
+                p1 = k / nvox
+                return (0.0 if k < nvox else 1.0, 1.0 if k > 0 else 0.0, p1, float(np.sqrt(p1 * (1.0 - p1))))
             # the 24 channel files are written in the background, each channel staying resident (uint8) for GridCreator
             for ch, name in enumerate(af3_encoding.CHANNEL_NAMES):
                 p = os.path.join(self.AF3_encodings, f"{name}_encoding.mrc")
@@ -136,7 +144,7 @@ class DataPreprocessor:
 
                 def write(p=p, ch=ch):
                     mrc.write_mrc(p, u8[ch].cpu().numpy().astype(np.float32), voxel_size=(1.0, 1.0, 1.0), origin=hd.origin, mapc=hd.mapc,
-                                  mapr=hd.mapr, maps=hd.maps, nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart)
+                                  mapr=hd.mapr, maps=hd.maps, nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart, stats=stats01(ones[ch]))
                 handoff.register_file(p, u8[ch], hdn, writer=write)
             if self.write_files == "sync":                    # the 24 writers run on the file pool's threads; all joined here
                 for name in af3_encoding.CHANNEL_NAMES:

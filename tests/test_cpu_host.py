@@ -36,6 +36,21 @@ def test_mrc_round_trip_and_axis_orders(tmp_path):
         mrc.read_mrc(p)
 
 
+def test_mrc_header_stats_of_a_binary_volume_from_its_count(tmp_path):
+    """DataPreprocessor.create_AF3_encodings hands write_mrc the statistics of a 0/1 channel computed from one count
+    (mica_amd/preprocessing.py); the file must be byte-identical to the one whose statistics come from the four float64 passes."""
+    rng = np.random.default_rng(11)
+    for dens, shape in ((1e-3, (40, 36, 44)), (0.37, (16, 20, 12)), (0.0, (8, 8, 8)), (1.0, (8, 8, 8))):
+        v = (rng.random(shape) < dens).astype(np.float32)
+        k, n = float(v.sum(dtype=np.float64)), float(v.size)
+        p1 = k / n
+        st = (0.0 if k < n else 1.0, 1.0 if k > 0 else 0.0, p1, float(np.sqrt(p1 * (1.0 - p1))))
+        a, b = str(tmp_path / "a.mrc"), str(tmp_path / "b.mrc")
+        mrc.write_mrc(a, v, origin=(1.5, -2.0, 3.0), nxstart=4)
+        mrc.write_mrc(b, v, origin=(1.5, -2.0, 3.0), nxstart=4, stats=st)
+        assert open(a, "rb").read() == open(b, "rb").read(), dens
+
+
 def test_mrc_reader_against_hand_packed_mrc2014_headers(tmp_path):
     """The reader against files packed here word by word from the MRC2014 layout (words 1-10 nx ny nz mode n[xyz]start m[xyz], 11-16
     cell, 17-19 mapc mapr maps, 20-22 dmin dmax dmean, 23 ispg, 24 nsymbt, 50-52 origin, 53 'MAP ', 54 machine stamp, 55 rms), i.e.
@@ -497,3 +512,25 @@ def test_handoff_registry_validity(tmp_path):
         handoff.wait_file(p)
     assert handoff.lookup_file(p) is None
     handoff.clear()
+
+
+def test_engine_methods_run_under_the_engines_lock():
+    """A context is not thread-safe (include/mica_hip.h) and the tile-file writer shares the tiler's engine from its own thread:
+    every public Engine method takes the engine's re-entrant lock (mica_amd/engine.py)."""
+    import threading
+    from mica_amd.engine import Engine
+
+    public = [n for n, m in vars(Engine).items() if callable(m) and not n.startswith("_")]
+    assert {"gather_tiles", "forward_tiles", "forward_records", "zoom_cubic", "close", "load_state_dict"} <= set(public)
+    assert all(hasattr(getattr(Engine, n), "__wrapped__") for n in public)
+    e = object.__new__(Engine)                 # no context: close() is the one method that needs nothing but the library handle
+    e.call_lock = threading.RLock()
+    seen = []
+
+    class Lib:
+        @staticmethod
+        def mica_destroy(h):
+            seen.append((h, e.call_lock._is_owned()))
+    e.lib, e._h = Lib, 1234
+    e.close()
+    assert seen == [(1234, True)] and e._h is None and not e.call_lock._is_owned()
