@@ -757,13 +757,15 @@ constexpr int DW_LX = DW_X + 2;
 // CQ = channel quads per workgroup (64 * CQ threads): 4 = 16 channels, two workgroups per CU; 8 = 32 channels = one full
 // 128-B line per voxel, one workgroup of eight waves per CU.  With 16 channels every access is a 64-B piece of a 1-KB
 // voxel row and the kernel saturated at ~4.5 TB/s of actual traffic; prep-style contiguous streams reach 5.4.
-template <int YO, int CQ> struct DwGeo {
-    static constexpr int Y = 4 * YO, LY = Y + 2, DWC = 4 * CQ, NT = 64 * CQ;
+// NYQ = y groups of threads: the column is 16(x) x NYQ*YO(y) and the workgroup 16 * CQ * NYQ threads; <2, 8, 8> covers the same 16 x 16 x 32
+// column as <4, 8, 4> with 16 waves of two outputs per thread instead of 8 waves of four (half the registers, four waves per SIMD)
+template <int YO, int CQ, int NYQ = 4> struct DwGeo {
+    static constexpr int Y = NYQ * YO, LY = Y + 2, DWC = 4 * CQ, NT = 16 * CQ * NYQ;
     static constexpr int PLANE = DW_LX * LY * DWC;     // floats per ring plane
 };
 
-template <int YO, int CQ>
-__global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(const float* __restrict__ x, Dims d, int C,
+template <int YO, int CQ, int NYQ = 4>
+__global__ __launch_bounds__(16 * CQ * NYQ, CQ == 4 ? 2 : 1) void depthwise_kernel(const float* __restrict__ x, Dims d, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ scale, const float* __restrict__ w27,
                                                         const float* __restrict__ bias, float* __restrict__ out,
@@ -771,7 +773,8 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
     // vs: floats between consecutive voxels of a channel slab in x and out - C for plain NDHWC, the channel block (32) for the
     // blocked raw layout [C / vs][V][vs] (common.h), in which a 32-channel slab is ONE contiguous run of memory
     extern __shared__ __attribute__((aligned(16))) float ring[];   // [3][LY][LX][16] ; reused for the statistics merge
-    constexpr int DW_Y = DwGeo<YO, CQ>::Y, DW_LY = DwGeo<YO, CQ>::LY, DW_PLANE = DwGeo<YO, CQ>::PLANE, DW_C = 4 * CQ, NT = 64 * CQ;
+    using Geo = DwGeo<YO, CQ, NYQ>;
+    constexpr int DW_Y = Geo::Y, DW_LY = Geo::LY, DW_PLANE = Geo::PLANE, DW_C = 4 * CQ, NT = Geo::NT, RL = NT / CQ;   // RL threads share a channel quad
     const int b = blockIdx.y;
     const int V = d.D * d.H * d.W;
     const int tid = threadIdx.x;
@@ -960,7 +963,7 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
         float4* sg = reinterpret_cast<float4*>(ring);
         sg[tid] = gsum;
         __syncthreads();
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int off = RL / 2; off > 0; off >>= 1) {
             if (tid / CQ < off) {
                 const float4 o = sg[tid + off * CQ];
                 float4 a = sg[tid];
@@ -983,8 +986,8 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
         shn[tid * 4 + j] = sn; shm[tid * 4 + j] = mean_; shq[tid * 4 + j] = m2;
     }
     __syncthreads();
-    const int rl = tid / CQ;                       // 0..63 within the channel quad
-    for (int off = 32; off > 0; off >>= 1) {
+    const int rl = tid / CQ;                       // 0..RL-1 within the channel quad
+    for (int off = RL / 2; off > 0; off >>= 1) {
         if (rl < off) {
             const int o = tid + off * CQ;
 #pragma unroll
@@ -1014,15 +1017,15 @@ __global__ __launch_bounds__(64 * CQ, CQ == 4 ? 2 : 1) void depthwise_kernel(con
 }
 
 // Returns the number of statistics partials per (tile, channel) written to stats_ws (when non-null).
-template <int YO, int CQ>
+template <int YO, int CQ, int NYQ = 4>
 static void launch_depthwise_t(const float* x, int B, Dims d, int C, const float* mean, const float* rstd, const float* scale,
                                const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, int ntx, int nty, int vs, hipStream_t st) {
-    using Gm = DwGeo<YO, CQ>;
+    using Gm = DwGeo<YO, CQ, NYQ>;
     const size_t lds = (3 * Gm::PLANE + 27 * Gm::DWC) * sizeof(float);
     static PerDeviceOnce once;
-    once.run([&](int) { (void)hipFuncSetAttribute((const void*)depthwise_kernel<YO, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    once.run([&](int) { (void)hipFuncSetAttribute((const void*)depthwise_kernel<YO, CQ, NYQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     dim3 grid((unsigned)(ntx * nty * (C / Gm::DWC)), B);
-    hipLaunchKernelGGL((depthwise_kernel<YO, CQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, vs);
+    hipLaunchKernelGGL((depthwise_kernel<YO, CQ, NYQ>), grid, dim3(Gm::NT), lds, st, x, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, vs);
 }
 int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, const float* rstd,
                      const float* scale, const float* w27, const float* bias, float* out, float* stats_ws, float* gap_ws, hipStream_t st, int cblk) {
@@ -1035,7 +1038,11 @@ int launch_depthwise(const float* x, int B, Dims d, int C, const float* mean, co
     // 32-channel workgroups (full 128-B lines) when that still gives every CU at least two rounds of work
     if (C % 32 == 0 && (int64_t)ntx * ((d.H + 15) / 16) * (C / 32) * Bplan >= 256) {
         const int nty = (d.H + 15) / 16;
+#ifdef MICA_EXP_DW16      // development A/B (tools/exp/dw16.sh): 16 waves of two outputs per thread - 0.559-0.567 against 0.568-0.574 of 8 TB/s
+        launch_depthwise_t<2, 8, 8>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, vs, st);
+#else
         launch_depthwise_t<4, 8>(x, B, d, C, mean, rstd, scale, w27, bias, out, stats_ws, gap_ws, ntx, nty, vs, st);
+#endif
         return ntx * nty;
     }
     // enough workgroups to fill 256 CUs twice: halve the column height when C * batch is small

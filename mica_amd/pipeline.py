@@ -48,12 +48,14 @@ class SlabDownloader:
         self.error = None
 
         def alloc():
+            torch.cuda.set_device(out.device)        # page-locking registers with the CURRENT device's context: not device 0's on rank r
             for k in range(2):
                 self.stage[k] = torch.empty((self.C, min(grid, self.n0), *out.shape[2:]), dtype=out.dtype).pin_memory()
                 self.free[k].set()
 
         def unpack():
             from concurrent.futures import ThreadPoolExecutor
+            torch.cuda.set_device(out.device)
             with ThreadPoolExecutor(max_workers=4, thread_name_prefix="mica-slab-copy") as pool:      # numpy's copy releases the GIL
                 def piece(k, lo, hi, c0, c1):
                     self.host[c0:c1, lo:hi] = self.stage[k][c0:c1, :hi - lo].numpy()
@@ -149,7 +151,7 @@ class VolumePredictor:
     def predict_volume(self, vol: torch.Tensor, af_vol: torch.Tensor | None = None, to_host: bool = False):
         """vol f32[N0,N1,N2] on the GPU (already normalised, (x,y,z) order), af_vol f32 or uint8 [24,N0,N1,N2] or None.
         Returns the dict of four device volumes with the shapes/dtypes of utils/predict.py:459-462 - or, with `to_host`, the same
-        dict as numpy arrays (views of one pinned buffer), downloaded slab by slab while later tiles compute (SlabDownloader)."""
+        dict as numpy arrays (views of one host array), downloaded slab by slab while later tiles compute (SlabDownloader)."""
         e = self.e
         n0, n1, n2 = vol.shape
         T = int(e.lib.mica_tile_count(n0, n1, n2, self.grid))

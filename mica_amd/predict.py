@@ -275,12 +275,6 @@ class CryoEMPredictor:
                 return False, {}
             if self.resident is not None:
                 vols = self.run_inference_resident()
-                # the tile files the caller asked GridCreator for are complete when this returns (utils/modeler.py:755 deletes
-                # grids_path right after nnPred: nothing may still be writing into it)
-                for e in self.resident:
-                    if e is not None and e.writer is not None:
-                        handoff._join(e.writer)
-                handoff.flush()              # ... nor into the normalised map / the encodings, which it deletes as well (:756-757)
             else:
                 ok, dataset = self.prepare_data()
                 if not ok:
@@ -298,6 +292,13 @@ class CryoEMPredictor:
             self.logger.error(f"Prediction pipeline failed: {e}")
             return False, {}
         finally:
+            if self.resident is not None:
+                # the tile files the caller asked GridCreator for are complete when this returns - on every way out (utils/modeler.py:755
+                # deletes grids_path right after nnPred: nothing may still be writing into it)
+                for e in self.resident:
+                    if e is not None and e.writer is not None:
+                        handoff._join(e.writer)
+                handoff.flush()              # ... nor into the normalised map / the encodings, which it deletes as well (:756-757)
             if self.engine is not None:
                 self.engine.close()
                 self.engine = None

@@ -723,6 +723,15 @@ def test_handoff_modes_no_files_sync_files_and_foreign_encodings(tmp_path, weigh
     assert ok and pred.resident is None
     for k in v_none:
         assert np.array_equal(v_none[k], vols[k]), k
+    # a predictor that fails (no checkpoint) still returns only after the background writers: nnPred's caller deletes grids_path next
+    grids = str(tmp_path / "failing")
+    gc = GridCreator(quiet=True, write_files=True)
+    assert gc.create_normalized_map_grids(mp, os.path.join(grids, "normalized_map_grids"))["success"]
+    assert gc.create_AF3_encodings_grids(str(inp / "AF3_encodings"), os.path.join(grids, "AF3_encoding_grids"))["success"]
+    pred = CryoEMPredictor(str(tmp_path / "no_such_checkpoint.pth"), grids + "/", str(tmp_path / "out"), save_output=False, device="cuda", quiet=True)
+    assert pred.run_prediction() == (False, {}) and pred.resident is not None
+    assert len(glob.glob(os.path.join(grids, "*", "*.npz"))) + len(glob.glob(os.path.join(grids, "*", "*", "*.npz"))) == 50
+    assert all(w.done() for w in gc._writers)
     handoff.clear()
 
 
