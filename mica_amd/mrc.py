@@ -112,9 +112,13 @@ def write_mrc(path: str, data: np.ndarray, voxel_size=(1.0, 1.0, 1.0), origin=(0
     h[212:216] = bytes([0x44, 0x44, 0x00, 0x00])
     struct.pack_into("<f", h, 216, float(stats[3]))
     struct.pack_into("<i", h, 220, 0)
-    with open(path, "wb") as f:
+    le = np.ascontiguousarray(data.astype(data.dtype.newbyteorder("<"), copy=False))
+    with open(path, "wb", buffering=0) as f:
         f.write(bytes(h))
-        f.write(data.astype(data.dtype.newbyteorder("<"), copy=False).tobytes())
+        body = memoryview(le.reshape(-1)).cast("B")      # the array's own memory: no second copy of a 67-MB volume on its way out
+        done = 0
+        while done < body.nbytes:
+            done += f.write(body[done:])
 
 
 def transpose_to_xyz(data: np.ndarray, hd: MrcHeader):

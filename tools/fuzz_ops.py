@@ -1,13 +1,13 @@
 """Random-shape sweep of the single-op C-ABI entries (`mica_op_*`, include/mica_hip.h) against torch on the CPU:
 
-    python tools/fuzz_ops.py [seconds=240] [seed=0]
+    python tools/fuzz_ops.py [seconds=240] [seed=0] [big]
 
 Every case draws an op, channel counts, a box (edges 1..96, biased to the awkward ones: 1, odd, one over / under a tile edge, the
 production width 64) and a batch, runs the HIP kernel through the Engine and compares with torch's float32 result of the same op
 (`F.conv3d`, `F.instance_norm`, grouped conv) in the metric of tests/test_gpu_ops.py: max |got - ref| / max(|ref|, rms(ref)).
 The persistent convs walk (tile, channel block) items over one workgroup per CU with hand-counted wait states per chunk: item counts
 below / equal to / not divisible by the workgroup count, odd chunk counts, padded last chunks and ragged tiles on every face are
-what the sweep is after.  One line per case goes to stdout (a hang shows as the last line); the last line is the tally.
+what the sweep is after; `big` draws edges >= 15 and boxes four times the volume (item counts well above the 256 workgroups).  One line per case goes to stdout (a hang shows as the last line); the last line is the tally.
 TEST INFRASTRUCTURE (the comparator is torch on the CPU, nothing under oracle/ is needed)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +17,7 @@ from mica_amd.weights import synth_state_dict
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(seed)
 torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
 
@@ -32,9 +33,13 @@ def rand(shape, lo=-1.0, hi=1.0):
 
 
 EDGES = [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 20, 31, 32, 33, 48, 63, 64, 65, 66, 96]
+if BIG:
+    EDGES = [e for e in EDGES if e >= 15]
 
 
 def box(max_vox):
+    if BIG:
+        max_vox *= 4
     while True:
         d = [int(rng.choice(EDGES)) for _ in range(3)]
         if rng.random() < 0.3:
@@ -47,6 +52,8 @@ def case_conv3(eng, w_all):
     variant = int(rng.integers(0, 2))
     cin = int(rng.choice([1, 3, 8, 16, 17, 24, 32, 40, 64, 72, 96, 130, 192, 196, 200, 256, 384]))
     cout = int(rng.choice([64, 64, 128, 128, 256, 512] if variant == 1 else [32, 64, 96, 128, 160, 192, 256]))
+    if BIG and cin * cout > 128 * 256:                   # the float32 comparator runs on the host's cores
+        cin = int(rng.choice([3, 16, 24, 40, 64, 72]))
     dims, batch = box(40000 if cin * cout <= 128 * 128 else 12000), int(rng.integers(1, 4))
     x, w, b = rand((batch, cin, *dims)), rand((cout, cin, 3, 3, 3)) * (3.0 / (cin * 27)) ** 0.5, rand((cout,)) * 0.1
     got = eng.op_conv3d(x.cuda(), w.numpy(), b.numpy(), 3, variant=variant)
@@ -119,6 +126,6 @@ while time.time() - t0 < seconds:
     worst[key] = max(worst.get(key, 0.0), err / tol)
     print(f"{n:4d} {'ok ' if ok else 'BAD'} {err:.2e} (tol {tol:.0e})  {name}", flush=True)
 eng.close()
-print(f"{n} random cases in {time.time() - t0:.0f} s (seed {seed}), {bad} beyond tolerance; worst error / tolerance per op: "
+print(f"{n} random cases in {time.time() - t0:.0f} s (seed {seed}{', big boxes' if BIG else ''}), {bad} beyond tolerance; worst error / tolerance per op: "
       + ", ".join(f"{k} {v:.3f}" for k, v in sorted(worst.items())))
 sys.exit(1 if bad else 0)
