@@ -65,11 +65,13 @@ def register_file(path: str, tensor: torch.Tensor, header, writer=None) -> FileE
     """`writer()` (optional) writes the file; it runs on a background thread, and whoever needs the FILE (`wait_file`, process exit)
     joins it.  Without a writer the file is taken to exist already."""
     e = FileEntry(tensor, header)
+    evicted = []
     with _LOCK:
         _FILES[_key(path)] = e
         while len(_FILES) > MAX_FILE_ENTRIES:
-            _, old = _FILES.popitem(last=False)
-            old.done.wait()
+            evicted.append(_FILES.popitem(last=False)[1])
+    for old in evicted:                      # outside the lock: their writers may still be on their way to the disk
+        old.done.wait()
     if writer is None:
         e.stamp = _stamp(path)
         e.done.set()
@@ -161,7 +163,7 @@ def _unmark(e):
         pass
 
 
-def _join(writer):
+def join_writer(writer):
     """Join a tile-file writer whose files nobody is waiting for any more; its error, if any, has nowhere to go but the log."""
     if writer is None:
         return
@@ -190,7 +192,7 @@ def register_grids(output_dir: str, entry: GridEntry):
         while len(_GRIDS) > MAX_GRID_ENTRIES:
             evicted.append(_GRIDS.popitem(last=False)[1])
     for e in ([old] if old is not None else []) + evicted:
-        _join(e.writer)
+        join_writer(e.writer)
         _unmark(e)
 
 
@@ -216,7 +218,7 @@ def drop_grids(output_dir: str, cancel_files: bool = False):
         if e.writer is not None:
             if cancel_files:
                 e.writer.cancel()
-            _join(e.writer)
+            join_writer(e.writer)
         _unmark(e)
 
 
@@ -228,7 +230,7 @@ def flush():
     for e in fs:
         e.done.wait()
     for g in gs:
-        _join(g.writer)
+        join_writer(g.writer)
 
 
 def clear():

@@ -297,7 +297,7 @@ class CryoEMPredictor:
                 # deletes grids_path right after nnPred: nothing may still be writing into it)
                 for e in self.resident:
                     if e is not None and e.writer is not None:
-                        handoff._join(e.writer)
+                        handoff.join_writer(e.writer)
                 handoff.flush()              # ... nor into the normalised map / the encodings, which it deletes as well (:756-757)
             if self.engine is not None:
                 self.engine.close()
