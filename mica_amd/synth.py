@@ -97,6 +97,9 @@ CASES64 = {
     "w2022g6": (2022, 6.0, 31), "w7g3": (7, 3.0, 33), "w99g10": (99, 10.0, 33), "zeroaf_w2022g6": (2022, 6.0, 33),
     "blob": None, "heavy": None,
     "w99g10_s101": (99, 10.0, 101), "w99g10_s102": (99, 10.0, 102), "w99g10_s103": (99, 10.0, 103), "w99g10_s104": (99, 10.0, 104),
+    # two more input seeds for each of the other two uniform weight sets, and two further weight seeds
+    "w7g3_s201": (7, 3.0, 201), "w7g3_s202": (7, 3.0, 202), "w2022g6_s201": (2022, 6.0, 201), "w2022g6_s202": (2022, 6.0, 202),
+    "w31g6_s301": (31, 6.0, 301), "w57g10_s302": (57, 10.0, 302),
 }
 
 

@@ -3,7 +3,8 @@
 Run:  python oracle/gen_golden_r5.py [--check] [case ...]      (needs /root/reference; ~4 min per case on 8 cores)
 
 Every golden family that has a 64^3 fixture (three uniform weight sets, the zero-AF branch, the two round-4 stress
-families) plus FOUR more input seeds of the family that sits closest to the 1e-4 bar (weights seed 99 / gain 10, AF path) goes
+families) plus FOUR more input seeds of the family that sits closest to the 1e-4 bar (weights seed 99 / gain 10, AF path), two more
+input seeds for each of the other two uniform weight sets and two further weight seeds (mica_amd/synth.py::CASES64: sixteen tiles) goes
 through the reference's own `models.model.MICA` (reference models/model.py:331-348, imported unmodified) three times on ONE 64^3
 tile:
 

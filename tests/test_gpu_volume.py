@@ -327,6 +327,10 @@ def test_preprocessor_with_anisotropic_voxels_and_nan(tmp_path, eng):
     ref, _, _ = vo.normalise_map(raw, voxel_size=hd0.voxel_size)       # zoom factors in (x,y,z) order on axes 0,1,2 (:112-117)
     assert got.shape == ref.shape and np.array_equal(got, ref)
     assert np.allclose(hd.voxel_size, (1.0, 1.0, 1.0))
+    # the header statistics are float64 reductions on the GPU (preprocessing.py): the four float32 fields equal numpy's on the host copy
+    d64 = got.astype(np.float64)
+    assert (np.float32(hd.dmin), np.float32(hd.dmax), np.float32(hd.dmean), np.float32(hd.rms)) == \
+        (np.float32(d64.min()), np.float32(d64.max()), np.float32(d64.mean()), np.float32(d64.std()))
     # a NaN voxel poisons the whole map through the recursive prefilter: the reference reports failure (:163-165)
     bad = raw.copy(); bad[3, 4, 5] = np.nan
     from mica_amd.engine import MicaHipError
