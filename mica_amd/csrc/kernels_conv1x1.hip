@@ -34,11 +34,13 @@
 // lanes of a quad read one 128-byte line instead of two half-used ones) - bench.py 83.24 against 83.33 / 82.76 sub-grids/s on one box: the
 // vector-memory front end is not what the kernel waits on either.
 // LDS: two 16-KB stages of [chunk-in-pair 2][plane 4 = hi/lo x channel half][128 rows] 16-byte slots (a ds_read_b128 lane
-// group covers 16 consecutive slots), refilled one pair ahead: global loads for pair p+1 are issued before the MFMAs of
-// pair p and committed to LDS after them, one barrier per pair.
+// group covers 16 consecutive slots), refilled one pair ahead: global loads for pair p+1 are issued in step 0 of
+// pair p (behind that step's weight-fragment request: the in-order vector-memory queue, see the main loop) and committed to LDS after the
+// pair's MFMAs, one barrier per pair.
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace mica {
 
@@ -92,32 +94,34 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
         return w;
     };
     float4 st[2][2];
+    // Exactly four 16-byte loads per thread and pair, whatever the source kind, the tile's raggedness or the parity of the chunk count
+    // (rows beyond the volume and a missing second chunk re-read a valid address; commit() writes zeros for them): the number of loads in
+    // flight is then a compile-time fact, and the waits on the weight fragments can leave these loads outstanding (`s_waitcnt vmcnt(n)`
+    // with n > 0) - behind a per-lane `if (v < V)` the compiler has to assume none was issued and waits for everything.
     auto fetch = [&](int pair) {
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            const int gch = 2 * pair + cc;
-            st[cc][0] = st[cc][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gch >= total_chunks) continue;
+            const int gch = min(2 * pair + cc, total_chunks - 1);
             const Where w = where(gch);
             const Conv1Src& s = src.s[w.si];
             if (s.kind == 1) {                               // raw: item = (row, 8-channel half)
                 const int row = tid >> 1, kh = tid & 1;
-                const int v = v0 + row;
-                if (v < V) {
-                    // plain NDHWC [V][Cs], or the blocked raw layout [Cs / cblk][V][cblk] (a chunk pair = one 32-channel block)
-                    const int Cs = s.chunks_total * 16, cb = s.cblk > 0 ? s.cblk : Cs, ch = (s.chunk_off + w.lc) * 16 + kh * 8;
-                    const float* p = reinterpret_cast<const float*>(s.p) + (int64_t)b * V * Cs + (int64_t)(ch / cb) * V * cb + (int64_t)v * cb + ch % cb;
-                    st[cc][0] = *reinterpret_cast<const float4*>(p);
-                    st[cc][1] = *reinterpret_cast<const float4*>(p + 4);
-                }
+                const int v = min(v0 + row, V - 1);
+                // plain NDHWC [V][Cs], or the blocked raw layout [Cs / cblk][V][cblk] (a chunk pair = one 32-channel block)
+                // (cblk is 0 or 32 - launch_conv1x1 refuses anything else -: no division in the address)
+                const int Cs = s.chunks_total * 16, ch = (s.chunk_off + w.lc) * 16 + kh * 8;
+                const bool blocked = s.cblk == 32;
+                const int cb = blocked ? 32 : Cs, blk = blocked ? ch >> 5 : 0, within = blocked ? ch & 31 : ch;
+                const float* p = reinterpret_cast<const float*>(s.p) + (int64_t)b * V * Cs + (int64_t)blk * V * cb + (int64_t)v * cb + within;
+                st[cc][0] = *reinterpret_cast<const float4*>(p);
+                st[cc][1] = *reinterpret_cast<const float4*>(p + 4);
             } else {                                          // split: two 16-byte pieces, piece = (row, plane)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int id = tid + C1_NT * k, plane = id & 3, row = id >> 2;
-                    const int v = v0 + row;
-                    if (v < V)
-                        st[cc][k] = *reinterpret_cast<const float4*>(reinterpret_cast<const _Float16*>(s.p) +
-                                                                     (((int64_t)b * s.chunks_total + s.chunk_off + w.lc) * V + v) * 32 + plane * 8);
+                    const int v = min(v0 + row, V - 1);
+                    st[cc][k] = *reinterpret_cast<const float4*>(reinterpret_cast<const _Float16*>(s.p) +
+                                                                 (((int64_t)b * s.chunks_total + s.chunk_off + w.lc) * V + v) * 32 + plane * 8);
                 }
             }
         }
@@ -150,7 +154,8 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int id = tid + C1_NT * k, plane = id & 3, row = id >> 2;
-                    *reinterpret_cast<float4*>(cb + (plane * C1_ROWS + row) * 16) = st[cc][k];
+                    const bool live = gch < total_chunks && v0 + row < V;
+                    *reinterpret_cast<float4*>(cb + (plane * C1_ROWS + row) * 16) = live ? st[cc][k] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         }
@@ -168,8 +173,8 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
     const _Float16* wb = wpk + (int64_t)b * wpk_bstride;
     const int rowbase = lr;
 
-    // weight fragments of (pair, kind): kind 0 = X(c), 1 = X(c'), 2 = Y.  They come straight from L1/L2 and are fetched one kind
-    // ahead (two register sets), so that their latency hides behind the previous kind's MFMAs
+    // weight fragments of (pair, kind): kind 0 = X(c), 1 = X(c'), 2 = Y.  They come straight from L1/L2 and are fetched two steps
+    // ahead (three register sets), so that their latency hides behind the MFMAs of the two steps before
     auto bload = [&](int pair, int kind, half8 (&bq)[NCT]) {
         const int c0 = 2 * pair, c1 = (2 * pair + 1 < total_chunks) ? 2 * pair + 1 : 2 * pair;
         const int gc = kind == 0 ? c0 : kind == 1 ? c1 : ((lg >> 1) ? c1 : c0);
@@ -178,27 +183,37 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
 #pragma unroll
         for (int c = 0; c < NCT; ++c) bq[c] = *reinterpret_cast<const half8*>(wp + (int64_t)c * 64 * 8);
     };
-    half8 bq[2][NCT];
+    half8 bq[3][NCT];
 
-    __syncthreads();                                  // norm table ready
-    fetch(0);
-    commit(0, smem);
-    bload(0, 0, bq[0]);
-    for (int p = 0; p < npairs; ++p) {
+    // Order of the vector-memory queue (round 5).  Loads retire in order: waiting for a weight fragment also waits for every load
+    // issued before it.  With the activation fetch of pair p+1 issued at the top of pair p, BEFORE the request for step 1's fragments,
+    // the wait at the start of step 1 forced the whole fetch to have landed after ONE step of MFMAs (a third of a pair) - the prefetch
+    // distance the kernel really had.  Now the fragments run two steps ahead (three register sets, set = step of the pair) and the
+    // fetch is issued right behind the request made in step 0: the first wait that covers it is the one for the fragments requested in
+    // step 1, which are needed at step 0 of the NEXT pair - the fetch has the whole pair, as the commit at the end of it always assumed.
+    // The loop is peeled: every pair but the last issues the same, unconditional set of loads (fragments of step 2, the next pair's
+    // activations, the next pair's first two fragment sets) - behind a uniform `if (p + 1 < npairs)` the compiler has to assume the loads
+    // were NOT issued and its waits fall back to vmcnt(0), which is the one-step prefetch distance again.
+    const auto kind_of = [&](int q, int stp) { return 2 * q + 1 < total_chunks ? stp : (stp == 0 ? 0 : 2); };
+    auto run_pair = [&](int p, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         char* cur = smem + (p & 1) * C1_STAGE;
-        const bool has2 = 2 * p + 1 < total_chunks;   // the pair's second chunk exists (always, but for the last pair of an odd count)
-        if (p + 1 < npairs) fetch(p + 1);
+        const bool has2 = LAST ? 2 * p + 1 < total_chunks : true;     // only the last pair of an odd chunk count lacks its second chunk
         __syncthreads();                              // stage p is complete; nobody still reads the stage that commit(p+1) will overwrite
-        // three steps per pair: X(c), X(c'), Y - or X(c), Y, (nothing) when the second chunk is missing; the fragments of the next
-        // step are requested before this step's MFMAs (two register sets, set = step & 1; a pair's first step uses set 0, so after
-        // three steps the next pair's first fragments are moved from set 1 to set 0)
+        // three steps per pair: X(c), X(c'), Y - or X(c), Y when the second chunk is missing
 #pragma unroll
         for (int stp = 0; stp < 3; ++stp) {
             const int kind = has2 ? stp : (stp == 0 ? 0 : 2);
             if (!has2 && stp == 2) break;
-            // request the next step's fragments
-            if (stp + 1 < (has2 ? 3 : 2)) bload(p, has2 ? stp + 1 : 2, bq[(stp + 1) & 1]);
-            else if (p + 1 < npairs) bload(p + 1, 0, bq[(stp + 1) & 1]);
+            // request the fragments of the step after the next one (set (stp + 2) % 3)
+            if (stp == 0) {
+                if (has2) bload(p, 2, bq[2]);
+                if (!LAST) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch(p + 1);                     // behind step 0's fragment request: see above
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (!LAST) bload(p + 1, kind_of(p + 1, stp - 1), bq[stp - 1]);
             // A: X(cc) reads plane lg of chunk cc; Y reads the hi plane (lg & 1) of chunk (lg >> 1)
             const int aplane = kind == 0 ? lg : kind == 1 ? 4 + lg : (lg >> 1) * 4 + (lg & 1);
             const char* ap = cur + (aplane * C1_ROWS + rowbase) * 16;
@@ -206,19 +221,19 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
             for (int f = 0; f < 8; ++f) {
                 const half8 a = *reinterpret_cast<const half8*>(ap + f * 16 * 16);
 #pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[stp & 1][c], acc[f][c], 0, 0, 0);
+                for (int c = 0; c < NCT; ++c) acc[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[stp][c], acc[f][c], 0, 0, 0);
                 if (f & 1) __builtin_amdgcn_sched_barrier(0);     // keeps the LDS reads from being hoisted over the whole step (registers)
             }
         }
-        if (p + 1 < npairs) {
-            const int last = has2 ? 3 : 2;            // the next pair's first fragments sit in set last & 1
-            if (last & 1) {
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) bq[0][c] = bq[1][c];
-            }
-            commit(p + 1, smem + ((p + 1) & 1) * C1_STAGE);
-        }
-    }
+        if (!LAST) commit(p + 1, smem + ((p + 1) & 1) * C1_STAGE);
+    };
+    __syncthreads();                                  // norm table ready
+    fetch(0);
+    commit(0, smem);
+    bload(0, kind_of(0, 0), bq[0]);
+    bload(0, kind_of(0, 1), bq[1]);
+    for (int p = 0; p + 1 < npairs; ++p) run_pair(p, std::false_type{});
+    run_pair(npairs - 1, std::true_type{});
     if (bad) atomicOr(enc.err + b, bad);
 
     // ---- epilogue: 64 output channels per pass through the staging tile T[128][64 (+4)] ----
@@ -355,6 +370,7 @@ void launch_conv1x1(const Conv1Srcs& src, const _Float16* wpk, int64_t wpk_bstri
         // the norm table in LDS holds 512 channels per raw source (the widest tensor of the network); shapes are fixed by the
         // forward graph and checked by the single-op entry points
         if (src.s[i].kind == 1 && src.s[i].chunks_total * 16 > 512) { refuse_launch("conv1x1: raw source wider than 512 channels"); return; }
+        if (src.s[i].kind == 1 && src.s[i].cblk != 0 && (src.s[i].cblk != 32 || src.s[i].chunks_total % 2)) { refuse_launch("conv1x1: a blocked raw source has 32-channel blocks"); return; }
     }
     const int w = wino.p != nullptr ? (wino_kind == 2 ? 2 : 1) : 0;
 #define C1_GO(NCT)                                                                                                                      \
