@@ -27,7 +27,8 @@
 // ahead through a register ring, Cout = 256 as eight waves x two column tiles: 12-40 % SLOWER (<1> 747 -> 842 us, <2> 994 ->
 // 1158, <4> 2792 -> 3927): the register cost halves the workgroups per CU, and it is the number of independent workgroups on a
 // CU - one's VALU-heavy commit / epilogue beside another's MFMAs and a third's HBM waits - that keeps the three pipes busy, not
-// the bytes in flight.  Also tried: padding the stage planes and XOR-swizzling the epilogue tile against the 20 % LDS bank-conflict
+// the bytes in flight.  (Round 5 read the generated waits instead - tools/audit_waits.py - and found what that experiment had been
+// after without the register cost: see "Order of the vector-memory queue" at the main loop; 0.47 -> 0.57 of the HBM roofline.)  Also tried: padding the stage planes and XOR-swizzling the epilogue tile against the 20 % LDS bank-conflict
 // share the counters show (under a 32-bank and under a 64-bank model of the LDS): the counter went to 40 % and the kernels 2-4 %
 // slower both times; the kernel is not LDS-bound (LDS busy 21-32 % of the cycles), so the layout stays.
 // Tried in round 4 and dropped: fetching a raw chunk pair line-wise (thread = (row, 8-channel group of the pair's 32 channels): the four
