@@ -4,7 +4,7 @@ utils/preprocessing.py:111-133, 172-178, 283-298, utils/modeler.py:767-858 via o
 
 The fixed-shape tests of test_gpu_volume.py pin these against goldens of the reference's own code; this sweep draws the shapes nobody
 picked by hand - prime edges, one voxel, one over / under the tile edge, non-cubic boxes, tilings other than (48, 8), zoom factors that
-shrink and stretch - and demands bit equality every time.  MICA_FUZZ_SECONDS sets the duration per family (default 4 s: a few dozen
+shrink and stretch - and demands bit equality every time.  MICA_FUZZ_SECONDS sets the duration per family, MICA_FUZZ_SEED shifts the generators (default 4 s, seed 0: a few dozen
 cases in the regular run; profiles/r05_fuzz_volume.txt records a 120-s run)."""
 import os
 import time
@@ -18,6 +18,7 @@ from oracle import volume_oracle as vo
 
 pytestmark = pytest.mark.gpu
 SECONDS = float(os.environ.get("MICA_FUZZ_SECONDS", "4"))
+SEED = int(os.environ.get("MICA_FUZZ_SEED", "0"))           # added to every family's generator seed
 EDGES = [1, 2, 3, 5, 7, 8, 15, 16, 17, 31, 33, 47, 48, 49, 55, 56, 57, 63, 64, 65, 71, 96, 97, 100]
 
 
@@ -39,7 +40,7 @@ def _box(rng, max_vox):
 def test_sweep_gather_and_stitch(eng):
     """gather == the oracle's pad-and-slice tiler for every tile; stitch(gather(v)) == v; tilings (48, 8), (32, 16), (16, 8), (56, 4), (60, 2)."""
     from mica_amd.engine import Engine
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + SEED)
     engines = {64: eng}
     t0, n = time.time(), 0
     try:
@@ -76,7 +77,7 @@ def test_sweep_zoom_and_normalise(eng):
     percentile, clip and divide) == numpy's arithmetic, bit for bit, on random boxes and voxel sizes."""
     from mica_amd.preprocessing import DataPreprocessor
     dp = DataPreprocessor("unused.mrc", "unused", quiet=True, engine=eng)
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(12 + SEED)
     t0, n = time.time(), 0
     while time.time() - t0 < SECONDS:
         shape = _box(rng, 60000)
@@ -101,7 +102,7 @@ def test_sweep_af3_rasteriser(eng):
     atom clouds that hang over every face (atoms outside the box are dropped; exact halves round to even)."""
     from mica_amd import af3_encoding as ae
     from oracle import af3_oracle as ao
-    rng = np.random.default_rng(13)
+    rng = np.random.default_rng(13 + SEED)
     names_all = ["CA", "N", "C", "O", "CB", "CG", "HA", "OXT", "SD", "NZ"]
     res_all = ao.AMINO_ACIDS + ["MSE", "UNK"]
     t0, n = time.time(), 0
@@ -128,7 +129,7 @@ def test_sweep_point_kernels(eng):
     """threshold -> gather -> sub-voxel refinement -> NMS (Solver.clustering, utils/modeler.py:767-858) against the reference's numpy statements
     (oracle/cluster_oracle.py) on random boxes, thresholds and radii."""
     from oracle import cluster_oracle as co
-    rng = np.random.default_rng(14)
+    rng = np.random.default_rng(14 + SEED)
     t0, n = time.time(), 0
     while time.time() - t0 < SECONDS:
         shape = _box(rng, 120000)
