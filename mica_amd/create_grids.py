@@ -3,8 +3,10 @@ names, arguments, result dicts and .npz tile files, but the windows are cut by t
 from a volume resident on the GPU, and the volume STAYS resident: it is registered under the directory
 the caller asked to fill (mica_amd/handoff.py), where a `CryoEMPredictor(grids_path=...)` of the same
 process finds it and predicts without reading a single tile file.  The files themselves - the reference's
-on-disk wire format, what a predictor in ANOTHER process reads - are written by a background pool
-(`write_files=True`, the default) or not at all (`write_files=False`)."""
+on-disk wire format, what a predictor in ANOTHER process reads - are complete when a wrapper returns
+(`write_files="sync"`, the default: the reference's contract, utils/create_grids.py:159-174), written by a
+background pool behind the caller (`"background"`; mica_amd/solver_mirrors.py, the Solver-flow import shim
+of INTEGRATION.md, selects it) or not at all (`False`)."""
 from __future__ import annotations
 
 import logging
@@ -31,14 +33,18 @@ def _axis_perm(hd):
 
 
 class GridCreator:
-    def __init__(self, quiet=False, engine: Engine | None = None, device=0, write_files: bool | str = True):
+    def __init__(self, quiet=False, engine: Engine | None = None, device=0, write_files: bool | str | None = None):
         """write_files: produce the reference's `.npz` tile files (create_grids.py:159-174).
-          True (default) the wrappers `create_normalized_map_grids` / `create_AF3_encodings_grids` return as soon as the volume is
-                         resident and registered; the files follow from a background writer (`wait_for_files()` joins it; so do
-                         process exit and the `CryoEMPredictor` mirror of this process, whichever route it takes);
-          "sync"         the files are complete when a wrapper returns - for a consumer in this process that is NOT one of the
-                         mirrors (say the reference's own predictor behind a swapped GridCreator);
-          False          no files - for a caller that knows its predictor is the mirror in this process."""
+          "sync"         (default; also the environment's MICA_TILE_FILES when the argument is None) every file is complete when a
+                         wrapper returns, as at the reference's call sites (utils/modeler.py:684-706): any consumer - the reference's
+                         own CryoEMPredictor / CryoEMTestDataset behind a swapped GridCreator, a subprocess, an os.listdir - finds them;
+          "background"   (or True) the wrappers `create_normalized_map_grids` / `create_AF3_encodings_grids` return as soon as the
+                         volume is resident and registered; the files follow from a background writer (`wait_for_files()` joins it;
+                         so do process exit and the `CryoEMPredictor` mirror of this process, whichever route it takes).  For the
+                         Solver flow (getData -> nnPred -> rmtree), where nothing but the mirrors looks at the directory in between:
+                         mica_amd/solver_mirrors.py.  A file appears under its final name only when it is complete (written under a
+                         hidden name and renamed), so a foreign reader can find FEWER files than it expects, never a truncated one;
+          False / "none" no files - for a caller that knows its predictor is the mirror in this process."""
         self.quiet = quiet
         self.logger = logging.getLogger(__name__)
         self.processed_count = 0
@@ -46,7 +52,15 @@ class GridCreator:
         self.failed_entries = []
         self._engine = engine
         self._device = device
-        self.write_files = bool(write_files)
+        if write_files is None:
+            write_files = os.environ.get("MICA_TILE_FILES", "sync")
+        if write_files is True:
+            write_files = "background"
+        if write_files in (False, "none", "false", "0"):
+            write_files = "none"
+        if write_files not in ("sync", "background", "none"):
+            raise ValueError("write_files must be 'sync', 'background' (True) or 'none' (False)")
+        self.write_files = write_files != "none"
         self.sync_files = write_files == "sync"
         self._writers = []
 
@@ -137,6 +151,8 @@ class GridCreator:
 
     def _start_writer(self, volume4, table, targets, grid_size, padding, hd, file_dtype, min_grid_max=None):
         eng = self._eng(grid_size + 2 * padding)
+        # a long-lived creator (one instance tiling many maps) does not keep every finished writer: failed ones stay for wait_for_files
+        self._writers = [w for w in self._writers if not (w.done() and w.error is None)]
         w = handoff.TileFileWriter(eng, volume4, table, targets, grid_size, padding,
                                    self._constant_members(volume4.shape[1:], grid_size, padding, hd), file_dtype=file_dtype,
                                    min_grid_max=min_grid_max).start()
@@ -190,7 +206,8 @@ class GridCreator:
             writer = None
             if self.write_files:
                 writer = self._start_writer(vol[None], table, [(output_dir, "normalized_map_grid")], grid_size, padding, hd, file_dtype)
-            handoff.register_grids(output_dir, handoff.GridEntry("map", vol, grid_size, padding, offset=offset, writer=writer))
+            handoff.register_grids(output_dir, handoff.GridEntry("map", vol, grid_size, padding, offset=offset, writer=writer,
+                                                                 sources=(normalized_map_path,)))
             if self.sync_files:
                 self.wait_for_files()
             self.logger.info(f"Created {n} grids from {os.path.basename(normalized_map_path)}")
@@ -257,7 +274,8 @@ class GridCreator:
                     if chans[:len(AF3_TYPES)] == tuple(AF3_TYPES):
                         os.makedirs(output_dir, exist_ok=True)
                         handoff.register_grids(output_dir, handoff.GridEntry("af3", vol[:len(AF3_TYPES)], grid_size, padding,
-                                                                             channels=chans[:len(AF3_TYPES)], writer=writer))
+                                                                             channels=chans[:len(AF3_TYPES)], writer=writer,
+                                                                             sources=tuple(files[q] for q, r in zip(order, loaded) if r is not None)))
         if self.sync_files:
             self.wait_for_files()
         return {"success": len(ok) > 0, "successful_channels": len(ok), "failed_channels": bad, "total_channels": len(files),

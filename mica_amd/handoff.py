@@ -63,15 +63,19 @@ class FileEntry:
 
 def register_file(path: str, tensor: torch.Tensor, header, writer=None) -> FileEntry:
     """`writer()` (optional) writes the file; it runs on a background thread, and whoever needs the FILE (`wait_file`, process exit)
-    joins it.  Without a writer the file is taken to exist already."""
+    joins it.  Without a writer the file is taken to exist already.  A caller that removes an older file of the same name first
+    calls `drop_file(path)` before it does (that joins the older writer); an entry still registered for the path is joined here."""
     e = FileEntry(tensor, header)
     evicted = []
     with _LOCK:
+        old = _FILES.pop(_key(path), None)   # a second write of the same path (a re-run, a second map in the same directory)
+        if old is not None:
+            evicted.append(old)
         _FILES[_key(path)] = e
         while len(_FILES) > MAX_FILE_ENTRIES:
             evicted.append(_FILES.popitem(last=False)[1])
-    for old in evicted:                      # outside the lock: their writers may still be on their way to the disk
-        old.done.wait()
+    for old in evicted:                      # outside the lock: their writers may still be on their way to the disk - the new writer
+        old.done.wait()                      # of the same path must not start before the old one has closed its file
     if writer is None:
         e.stamp = _stamp(path)
         e.done.set()
@@ -105,7 +109,8 @@ def files_under(directory: str, suffix: str = ""):
     """Paths registered by this process inside `directory` (their files may still be on their way to the disk)."""
     d = _key(directory)
     with _LOCK:
-        return [k for k in _FILES if os.path.dirname(k) == d and k.endswith(suffix)]
+        keys = [k for k in _FILES if os.path.dirname(k) == d and k.endswith(suffix)]
+    return [k for k in keys if lookup_file(k) is not None]      # not the ones whose file the caller has deleted or rewritten since
 
 
 def lookup_file(path: str) -> FileEntry | None:
@@ -149,10 +154,19 @@ class GridEntry:
     writer: "TileFileWriter | None" = None
     marker: str | None = None            # a hidden file beside the directory, see register_grids
     inode: int | None = None             # of the directory when it was registered
+    sources: tuple = ()                  # the MRC files the volume was taken from (their FileEntry copies are dropped with the entry)
+    dtype: object = None                 # of the volume, kept when `release()` has given the tensor back
+    _shape: tuple = ()
 
     @property
     def shape(self):
-        return tuple(self.volume.shape[-3:])
+        return tuple(self.volume.shape[-3:]) if self.volume is not None else self._shape
+
+    def release(self):
+        """The consumer is done with the volume: drop the tensor (HBM), keep what describes the route that was taken."""
+        if self.volume is not None:
+            self.dtype, self._shape = self.volume.dtype, tuple(self.volume.shape[-3:])
+            self.volume = None
 
 
 def _unmark(e):
@@ -360,10 +374,17 @@ class TileFileWriter:
         self._count_lock = threading.Lock()
         self._thread = threading.Thread(target=self._feed, name="mica-tile-writer", daemon=False)
         self._started = False
+        self._ready = None                   # event on the caller's stream behind the kernels that produced `volume`
 
     def start(self):
+        """Called on the thread that produced `volume`: whatever that thread has queued on its current stream (the transpose / stack
+        kernels of GridCreator._device_volume run asynchronously) is ordered in front of the writer's gathers, which run on a
+        private stream of the feeder thread (advisor, round 5: with `wait()` right behind `start()` the first chunks could be cut
+        from a half-written volume)."""
         for d, _ in self.targets:
             os.makedirs(d, exist_ok=True)
+        self._ready = torch.cuda.Event()
+        self._ready.record(torch.cuda.current_stream(self.engine.device))
         self._started = True
         self._thread.start()
         return self
@@ -407,7 +428,11 @@ class TileFileWriter:
         i, j, k, di, dj, dk = (int(v) for v in row)
         head, body, tail = self.layout.pieces(g, {"i": i, "j": j, "k": k, "di": di, "dj": dj, "dk": dk}, SCALAR_ORDER)
         d, prefix = self.targets[c]
-        fd = os.open(os.path.join(d, f"{prefix}_i{i}_j{j}_k{k}.npz"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        name = f"{prefix}_i{i}_j{j}_k{k}.npz"
+        # under a hidden name that no `*.npz` glob matches, renamed into place when complete: a reader outside this package (the
+        # reference's own dataset, another process) sees a whole tile file or none
+        part = os.path.join(d, f".{name}.{os.getpid()}.part")
+        fd = os.open(part, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
         try:
             todo = [head, body, tail]
             n = os.writev(fd, todo)
@@ -416,8 +441,15 @@ class TileFileWriter:
                 flat = head + bytes(body) + tail
                 while n < total:
                     n += os.write(fd, flat[n:])
-        finally:
+        except BaseException:
             os.close(fd)
+            try:
+                os.remove(part)
+            except OSError:
+                pass
+            raise
+        os.close(fd)
+        os.replace(part, os.path.join(d, name))
         with self._count_lock:
             self.written += 1
 
@@ -428,9 +460,11 @@ class TileFileWriter:
             self._go.wait(self.START_DELAY)
             torch.cuda.set_device(e.device)
             stream = torch.cuda.Stream(device=e.device)
+            stream.wait_event(self._ready)       # the volume's producers, queued by the thread that called start()
             C, W, T = self.volume.shape[0], self.W, len(self.table)
             pins = [_take_pinned(self.chunk * C * W ** 3).view(self.chunk, C, W, W, W) for _ in range(2)]
-            devs = [torch.empty((self.chunk, C, W, W, W), dtype=torch.float32, device=e.device) for _ in range(2)]
+            with torch.cuda.stream(stream):      # allocated on the stream that uses them: the caching allocator orders a later reuse
+                devs = [torch.empty((self.chunk, C, W, W, W), dtype=torch.float32, device=e.device) for _ in range(2)]
             inflight = [[], []]
             pool = _npz_pool()
             try:
@@ -457,9 +491,12 @@ class TileFileWriter:
                         f.exception()
                 for pbuf in pins:
                     _give_pinned(pbuf)
+                stream.synchronize()             # nothing of this writer is running when its staging tensors are released
         except Exception as ex:
             self.error = ex
             self._cancel.set()
+        finally:
+            self.volume = None                   # a finished writer does not keep a 0.5 + 3.2-GB volume alive (the GridEntry owns it)
 
 
 # One pool of writer threads and a small cache of pinned staging buffers for every TileFileWriter of the process: two writers (map and

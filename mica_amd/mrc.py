@@ -5,6 +5,7 @@ utils/preprocessing.py:98-107,138-148): data, voxel_size, origin, mapc/mapr/maps
 """
 from __future__ import annotations
 
+import os
 import struct
 from dataclasses import dataclass, field
 
@@ -113,12 +114,23 @@ def write_mrc(path: str, data: np.ndarray, voxel_size=(1.0, 1.0, 1.0), origin=(0
     struct.pack_into("<f", h, 216, float(stats[3]))
     struct.pack_into("<i", h, 220, 0)
     le = np.ascontiguousarray(data.astype(data.dtype.newbyteorder("<"), copy=False))
-    with open(path, "wb", buffering=0) as f:
-        f.write(bytes(h))
-        body = memoryview(le.reshape(-1)).cast("B")      # the array's own memory: no second copy of a 67-MB volume on its way out
-        done = 0
-        while done < body.nbytes:
-            done += f.write(body[done:])
+    # written under a hidden temporary name and renamed into place: a reader that is not one of this package's mirrors (which join
+    # the writer, handoff.wait_file) sees either no file or the complete one, never a truncated map
+    part = os.path.join(os.path.dirname(path) or ".", f".{os.path.basename(path)}.{os.getpid()}.part")
+    try:
+        with open(part, "wb", buffering=0) as f:
+            f.write(bytes(h))
+            body = memoryview(le.reshape(-1)).cast("B")      # the array's own memory: no second copy of a 67-MB volume on its way out
+            done = 0
+            while done < body.nbytes:
+                done += f.write(body[done:])
+        os.replace(part, path)
+    except BaseException:
+        try:
+            os.remove(part)
+        except OSError:
+            pass
+        raise
 
 
 def transpose_to_xyz(data: np.ndarray, hd: MrcHeader):

@@ -45,6 +45,7 @@ class CryoEMPredictor:
         self.use_optimized_batching = False
         self.optimal_batch_size = 1
         self.use_resident_volumes = True    # take the volumes a GridCreator of this process left on the GPU (handoff.py) instead of its files
+        self.keep_resident_volumes = False  # True: leave them registered after the prediction (a second predictor on the same grids_path)
         self.resident = None                # (map entry, AF3 entry or None) once select_processing_strategy found them
         self.engine = None
         self.sample_count = 0
@@ -299,6 +300,16 @@ class CryoEMPredictor:
                     if e is not None and e.writer is not None:
                         handoff.join_writer(e.writer)
                 handoff.flush()              # ... nor into the normalised map / the encodings, which it deletes as well (:756-757)
+                if not self.keep_resident_volumes:
+                    # the grids are consumed: give back the HBM behind them (0.5 + 3.2 GB of transposed volumes and as much again in
+                    # the MRC stage's copies at 512^3) instead of waiting for 32 newer entries to evict them.  The FILES stay: a second
+                    # predictor on the same grids_path reads them, like the reference.
+                    for d, e in zip(("normalized_map_grids", "AF3_encoding_grids"), self.resident):
+                        if e is not None:
+                            for f in e.sources:
+                                handoff.drop_file(f)
+                            handoff.drop_grids(os.path.join(self.grids_path, d))
+                            e.release()
             if self.engine is not None:
                 self.engine.close()
                 self.engine = None

@@ -23,11 +23,15 @@ _MAP_TYPES = {np.dtype(np.float32): 0, np.dtype(np.int8): 1, np.dtype(np.int16):
 
 
 class DataPreprocessor:
-    def __init__(self, map_path, AF3_results, quiet=False, engine: Engine | None = None, device=0, write_files: str = "sync"):
-        """write_files: "sync" (default) - the MRC files this stage is called for (the normalised map, the 24 encoding channels)
-        exist when its methods return, as at the reference's call sites (utils/modeler.py:675-683); "background" - they are written
-        behind the caller's back (joined by `mica_amd.mrc.read_mrc`, by the predictor mirror and at process exit): for a caller whose
-        next stage is the `GridCreator` mirror of this process, which takes the volumes from the GPU either way (mica_amd/handoff.py)."""
+    def __init__(self, map_path, AF3_results, quiet=False, engine: Engine | None = None, device=0, write_files: str | None = None):
+        """write_files: "sync" (default; also the environment's MICA_MRC_FILES when the argument is None) - the MRC files this stage
+        is called for (the normalised map, the 24 encoding channels) exist when its methods return, as at the reference's call sites
+        (utils/modeler.py:675-683); "background" - they are written behind the caller's back (joined by `GridCreator.load_volume`,
+        by the predictor mirror before it returns and at process exit): for the Solver flow, whose next stage is the `GridCreator`
+        mirror of this process, which takes the volumes from the GPU either way (mica_amd/handoff.py; mica_amd/solver_mirrors.py
+        selects it).  Either way a file appears under its name only when it is complete (hidden temporary name + rename)."""
+        if write_files is None:
+            write_files = os.environ.get("MICA_MRC_FILES", "sync")
         if write_files not in ("sync", "background"):
             raise ValueError("write_files must be 'sync' or 'background'")
         self.write_files = write_files
@@ -93,6 +97,7 @@ class DataPreprocessor:
                               maps=hd.maps, nxstart=hd.nxstart, nystart=hd.nystart, nzstart=hd.nzstart, stats=stats)
             # the normalised map stays on the GPU for GridCreator (mica_amd/handoff.py); the file the reference's call site expects
             # (utils/modeler.py:684-690) is written behind the caller's back and joined by whoever reads it
+            handoff.drop_file(path)                # a writer of an earlier run still on its way to this very path is joined first
             if os.path.exists(path):
                 os.remove(path)
             handoff.register_file(path, t, hdn, writer=write)
@@ -146,6 +151,7 @@ class DataPreprocessor:
             # the 24 channel files are written in the background, each channel staying resident (uint8) for GridCreator
             for ch, name in enumerate(af3_encoding.CHANNEL_NAMES):
                 p = os.path.join(self.AF3_encodings, f"{name}_encoding.mrc")
+                handoff.drop_file(p)               # joins a writer of an earlier run (a second map in the same AF3_results directory)
                 if os.path.exists(p):
                     os.remove(p)
 

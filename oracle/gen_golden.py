@@ -140,15 +140,14 @@ def _generate():
     rbb = sm(torch.cat((rb[:, :1], rb[:, 2:]), dim=1)); rcc = sm(torch.cat((rc[:, :1], rc[:, 2:]), dim=1))
     raa = sm(ra[:, 1:, :, :, :]); rpp = torch.max(raa, 1)[1]
     assert torch.equal(rbb[:, 2], pb) and torch.equal(rcc[:, 2], pc) and torch.equal(raa, pa) and torch.equal(rpp, pp)
-    st = 4
+    from oracle._check import LATTICE_OFFSET, LATTICE_STRIDE, lattice
     np.savez_compressed(os.path.join(OUT, "model_S64_af_sub.npz"),
-                        bb=rb.numpy()[..., ::st, ::st, ::st], ca=rc.numpy()[..., ::st, ::st, ::st],
-                        aa=ra.numpy()[..., ::st, ::st, ::st],
-                        bb_prob=pb.numpy()[..., ::st, ::st, ::st], ca_prob=pc.numpy()[..., ::st, ::st, ::st],
-                        aa_prob=pa.numpy()[..., ::st, ::st, ::st], aa_pred=pp.numpy()[..., ::st, ::st, ::st].astype(np.uint8),
+                        bb=lattice(rb.numpy()), ca=lattice(rc.numpy()), aa=lattice(ra.numpy()),
+                        bb_prob=lattice(pb.numpy()), ca_prob=lattice(pc.numpy()),
+                        aa_prob=lattice(pa.numpy()), aa_pred=lattice(pp.numpy()).astype(np.uint8),
                         mean=np.array([rb.mean(), rc.mean(), ra.mean()], dtype=np.float64),
                         std=np.array([rb.std(), rc.std(), ra.std()], dtype=np.float64),
-                        seed=31, afp=1e-3, S=64, stride=st)
+                        seed=31, afp=1e-3, S=64, stride=LATTICE_STRIDE, offset=np.array(LATTICE_OFFSET))
     print("model 64 oracle-vs-ref", d, "ref s", t_ref, "oracle s", t_or, flush=True)
 
     # ---- predictor end to end: 60x40x40 map = 2 tiles, reference CryoEMPredictor -----
@@ -225,8 +224,13 @@ def _generate():
                              "percentile": pct, "sha256": sha(out)}
     json.dump(norm, open(os.path.join(OUT, "normaliser.json"), "w"))
 
-    json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
-    print(json.dumps(manifest, indent=1))
+    mp = os.path.join(OUT, "manifest.json")
+    if os.path.exists(mp):                               # the later generators (r2, r4, r5, noise_floor) keep their records in the same file
+        old = json.load(open(mp))
+        old.update(manifest)
+        manifest = old
+    json.dump(manifest, open(mp, "w"), indent=1)
+    print(json.dumps({k: v for k, v in manifest.items() if k not in ("S64", "noise_floor")}, indent=1))
 
 
 if __name__ == "__main__":

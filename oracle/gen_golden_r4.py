@@ -79,16 +79,17 @@ def gen(kind, manifest):
                         bb64=t64[0], ca64=t64[1], aa64=t64[2], ref32_scaled=r32s, S=S)
     print(kind, "S16 oracle-vs-ref", d, "reference float32 vs float64", r32s.tolist(), flush=True)
     # ---- one 64^3 tile ----
-    S, st = 64, 4
+    S = 64
     w, x, af = case_inputs(kind, S)
     with torch.no_grad():
         rb, rc, ra = m(x, af)
     pb, pc, pa, pp = mo.postprocess(rb, rc, ra)
+    from oracle._check import LATTICE_OFFSET, LATTICE_STRIDE, lattice
     np.savez_compressed(os.path.join(OUT, f"r4_{kind}_S64_sub.npz"),
-                        bb=rb.numpy()[..., ::st, ::st, ::st], ca=rc.numpy()[..., ::st, ::st, ::st], aa=ra.numpy()[..., ::st, ::st, ::st],
-                        bb_prob=pb.numpy()[..., ::st, ::st, ::st], ca_prob=pc.numpy()[..., ::st, ::st, ::st],
-                        aa_prob=pa.numpy()[..., ::st, ::st, ::st], aa_pred=pp.numpy()[..., ::st, ::st, ::st].astype(np.uint8),
-                        S=64, stride=st)
+                        bb=lattice(rb.numpy()), ca=lattice(rc.numpy()), aa=lattice(ra.numpy()),
+                        bb_prob=lattice(pb.numpy()), ca_prob=lattice(pc.numpy()),
+                        aa_prob=lattice(pa.numpy()), aa_pred=lattice(pp.numpy()).astype(np.uint8),
+                        S=64, stride=LATTICE_STRIDE, offset=np.array(LATTICE_OFFSET))
     print(kind, "S64 done; logits rms", [float(t.pow(2).mean().sqrt()) for t in (rb, rc, ra)], flush=True)
 
 

@@ -99,11 +99,18 @@ def head(w, p, x):
 
 
 @torch.no_grad()
-def mica_forward(w, exp_map, af=None, return_intermediates=False):
+def mica_forward(w, exp_map, af=None, return_intermediates=False, dtype=torch.float32):
     """model.py:331-348.  exp_map f32[B,1,D,H,W], af f32[B,24,D,H,W] or None ->
-    (backbone f32[B,4,...], ca f32[B,4,...], aa f32[B,21,...]) logits, NCDHW."""
-    exp_map = torch.as_tensor(exp_map, dtype=torch.float32)
-    af = None if af is None else torch.as_tensor(af, dtype=torch.float32)
+    (backbone f32[B,4,...], ca f32[B,4,...], aa f32[B,21,...]) logits, NCDHW.
+
+    dtype=torch.float64 is the reference module after `MICA().double()` with the same float32 weights widened (what
+    oracle/gen_golden_r5.py and oracle/noise_floor.py --truth run as "the exact answer"): every op below then computes in
+    double.  Pinned bit for bit against the reference's own float64 run: S = 16 by tests/test_cpu_oracle.py against
+    tests/golden/truth64_S16_*.npz, whole 64^3 tiles by gen_golden_r5.py (manifest.json["oracle64_vs_reference64_maxabs"])."""
+    exp_map = torch.as_tensor(exp_map).to(dtype)
+    af = None if af is None else torch.as_tensor(af).to(dtype)
+    if dtype != torch.float32:
+        w = {k: _t(w, k).to(dtype) for k in w}
     inter = {}
     x = multi_scale_input(w, exp_map, af)
     inter["stem"] = x

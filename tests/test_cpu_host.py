@@ -514,6 +514,82 @@ def test_handoff_registry_validity(tmp_path):
     handoff.clear()
 
 
+def test_handoff_second_write_of_a_path_joins_the_first_and_deleted_files_are_not_listed(tmp_path):
+    """Advisor findings of round 5: (1) `register_file` for a path that still has a background writer (a re-run, a second map in the same
+    AF3_results directory) joins the older writer before the new one starts - two writers never stream into one path - and
+    `drop_file`, which DataPreprocessor calls before it removes the old file, joins it too; (2) `files_under` does not list entries
+    whose file the caller has deleted since (create_AF3_encodings_grids then says "No AF3 encoding files found" like the reference,
+    utils/create_grids.py:300-306)."""
+    import threading
+    import time
+    from mica_amd import handoff
+    handoff.clear()
+    p = str(tmp_path / "CA_encoding.mrc")
+    gate, log = threading.Event(), []
+
+    def slow():
+        gate.wait(5.0)
+        open(p, "wb").write(b"first")
+        log.append("first closed")
+
+    def second():
+        log.append("second started")
+        open(p, "wb").write(b"second!")
+    handoff.register_file(p, torch.zeros(3), header="hd", writer=slow)
+    threading.Timer(0.3, gate.set).start()
+    t0 = time.time()
+    handoff.register_file(p, torch.ones(3), header="hd", writer=second)      # returns only when the first writer has closed its file
+    assert log[0] == "first closed" and time.time() - t0 >= 0.25
+    handoff.wait_file(p)
+    assert log == ["first closed", "second started"] and open(p, "rb").read() == b"second!"
+    fe = handoff.lookup_file(p)
+    assert fe is not None and float(fe.tensor.sum()) == 3.0
+    # drop_file joins as well (what preprocessing.py does before os.remove)
+    gate.clear()
+    handoff.register_file(p, torch.zeros(3), header="hd", writer=slow)
+    threading.Timer(0.2, gate.set).start()
+    handoff.drop_file(p)
+    assert log[-1] == "first closed" and handoff.lookup_file(p) is None
+    # a file deleted by the caller is not listed any more
+    handoff.register_file(p, torch.zeros(3), header="hd", writer=second)
+    handoff.wait_file(p)
+    assert handoff.files_under(str(tmp_path), "_encoding.mrc") == [os.path.realpath(p)]
+    os.remove(p)
+    assert handoff.files_under(str(tmp_path), "_encoding.mrc") == []
+    handoff.clear()
+
+
+def test_file_modes_of_the_mirrors_and_of_the_solver_shim(monkeypatch):
+    """The drop-in classes keep the reference's contract by default ("sync": files complete when the call returns, advisor finding
+    of round 5); the environment or the Solver-flow shim selects the background writers."""
+    from mica_amd import solver_mirrors
+    from mica_amd.create_grids import GridCreator
+    from mica_amd.preprocessing import DataPreprocessor
+    monkeypatch.delenv("MICA_TILE_FILES", raising=False)
+    monkeypatch.delenv("MICA_MRC_FILES", raising=False)
+    g = GridCreator(quiet=True)
+    assert g.write_files and g.sync_files
+    assert DataPreprocessor("m.mrc", "x/AF3_results", quiet=True).write_files == "sync"
+    for arg, want in ((True, (True, False)), ("background", (True, False)), ("sync", (True, True)), (False, (False, False)), ("none", (False, False))):
+        g = GridCreator(quiet=True, write_files=arg)
+        assert (g.write_files, g.sync_files) == want, arg
+    with pytest.raises(ValueError):
+        GridCreator(quiet=True, write_files="later")
+    monkeypatch.setenv("MICA_TILE_FILES", "background")
+    monkeypatch.setenv("MICA_MRC_FILES", "background")
+    g = GridCreator(quiet=True)
+    assert g.write_files and not g.sync_files and DataPreprocessor("m.mrc", "x/AF3_results", quiet=True).write_files == "background"
+    assert GridCreator(quiet=True, write_files="sync").sync_files                       # an explicit argument wins
+    monkeypatch.delenv("MICA_TILE_FILES")
+    monkeypatch.delenv("MICA_MRC_FILES")
+    s = solver_mirrors.GridCreator(quiet=True)
+    assert isinstance(s, GridCreator) and s.write_files and not s.sync_files
+    d = solver_mirrors.DataPreprocessor("m.mrc", "x/AF3_results", quiet=True)
+    assert isinstance(d, DataPreprocessor) and d.write_files == "background"
+    from mica_amd.predict import CryoEMPredictor
+    assert solver_mirrors.CryoEMPredictor is CryoEMPredictor
+
+
 def test_engine_methods_run_under_the_engines_lock():
     """A context is not thread-safe (include/mica_hip.h) and the tile-file writer shares the tiler's engine from its own thread:
     every public Engine method takes the engine's re-entrant lock (mica_amd/engine.py)."""

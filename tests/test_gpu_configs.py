@@ -74,7 +74,7 @@ def test_config0_chained_plumbing_mrc_pdb_to_volumes(tmp_path, eng, weights):
     dp.resample_and_normalize_map()
     assert dp.normalized_map_path == str(inp / "resampled_normalized_map.mrc")
     assert dp.create_AF3_encodings(str(pdb)) is True
-    gc = GridCreator(quiet=True, engine=eng)
+    gc = GridCreator(quiet=True, engine=eng, write_files="background")         # the Solver-flow setting (mica_amd/solver_mirrors.py)
     grids = str(tmp_path / "grids")
     res_map = gc.create_normalized_map_grids(normalized_map_path=dp.normalized_map_path, output_dir=os.path.join(grids, "normalized_map_grids"))
     res_af = gc.create_AF3_encodings_grids(AF3_encodings_path=str(inp / "AF3_encodings"), output_dir=os.path.join(grids, "AF3_encoding_grids"),
@@ -109,7 +109,7 @@ def test_config0_chained_plumbing_mrc_pdb_to_volumes(tmp_path, eng, weights):
     assert ok and vols["amino_acid_probability"].shape == (20, 60, 50, 40)
     assert pred.sample_count == 4 and pred.use_optimized_batching is False
     # the predictor took the volumes GridCreator left on the GPU (mica_amd/handoff.py) - the encodings as uint8 -, not the files
-    assert pred.resident is not None and pred.resident[1] is not None and pred.resident[1].volume.dtype == torch.uint8
+    assert pred.resident is not None and pred.resident[1] is not None and pred.resident[1].dtype == torch.uint8
     # ... and the same class reading the FILES (what a predictor in another process does) returns the same volumes bit for bit
     cold = CryoEMPredictor(model_path=ck, grids_path=grids + "/", output_path=str(tmp_path / "out"), save_output=False, device="cuda", quiet=True)
     cold.use_resident_volumes = False

@@ -4,6 +4,7 @@ tiler unmodified under I/O-only `mrcfile` / `Bio` adapters): tiles, index tables
 normalised maps of every MRC mode the reference accepts, the 24-channel encodings.  Bit-exact throughout.
 Plus the whole path at BASELINE's stride-32 tiling (32, 16) on one rank and on two."""
 import hashlib
+import glob
 import json
 import os
 import socket
@@ -80,7 +81,8 @@ def test_gridcreator_wrappers_and_training_tiler_vs_reference_run_goldens(tmp_pa
     gdir = str(tmp_path / "grids" / "normalized_map_grids")
     res = gc.create_normalized_map_grids(p, gdir)
     assert sorted(res) == w["result_keys"] and {k: res[k] for k in w["result"]} == w["result"]
-    assert gc.wait_for_files() == res["grid_count"]            # the tile files follow from the background writer
+    # default write_files="sync" (the reference's contract): every file is there, complete, when the wrapper has returned
+    assert len(glob.glob(os.path.join(gdir, "*.npz"))) == res["grid_count"] and gc.wait_for_files() == 0
     assert sorted(os.listdir(gdir)) == w["files"]
     assert sha(np.stack([z["grid"] for z in _tiles_of(gdir, "normalized_map_grid")])) == w["tiles_sha256"]
     miss = gc.create_normalized_map_grids(str(tmp_path / "nope.mrc"), gdir)
@@ -95,7 +97,7 @@ def test_gridcreator_wrappers_and_training_tiler_vs_reference_run_goldens(tmp_pa
     adir = str(tmp_path / "grids" / "AF3_encoding_grids")
     res = gc.create_AF3_encodings_grids(str(edir), adir, parallel=False)
     assert sorted(res) == a["result_keys"] and {k: res[k] for k in a["result"]} == a["result"]
-    assert gc.wait_for_files() == res["total_grids"]
+    assert len(glob.glob(os.path.join(adir, "*", "*.npz"))) == res["total_grids"] and gc.wait_for_files() == 0
     assert sorted(os.listdir(adir)) == a["dirs"]
     for name, lay in a["layout"].items():
         d = os.path.join(adir, f"{name}_grids")

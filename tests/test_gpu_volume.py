@@ -252,7 +252,7 @@ def test_gridcreator_and_preprocessor_mirrors(tmp_path, eng):
     vol, off = vo.transpose_axes(ref, 1, 2, 3, [7, 6, 5])
     tiles, idx = vo.tile_volume(vol, 48, 8)
     assert res["success"] and res["grid_count"] == len(idx) == 4 and res["offset"] == off == [5.0, 6.0, 7.0]
-    assert gc.wait_for_files() == 4                                   # the tile files come from a background writer
+    assert gc.wait_for_files() == 0                                   # default "sync": nothing is left to wait for when the wrapper returns
     files = glob.glob(str(tmp_path / "grids" / "normalized_map_grids" / "*.npz"))
     assert len(files) == 4
     for t, (i, j, k, di, dj, dk) in enumerate(idx):
@@ -736,6 +736,49 @@ def test_handoff_modes_no_files_sync_files_and_foreign_encodings(tmp_path, weigh
     assert pred.run_prediction() == (False, {}) and pred.resident is not None
     assert len(glob.glob(os.path.join(grids, "*", "*.npz"))) + len(glob.glob(os.path.join(grids, "*", "*", "*.npz"))) == 50
     assert all(w.done() for w in gc._writers)
+    handoff.clear()
+
+
+def test_tile_writer_started_at_once_on_a_256_cube_cuts_the_finished_volume(tmp_path, eng):
+    """Advisor finding of round 5: TileFileWriter gathers on a private stream of its feeder thread, while the volume it cuts is produced
+    by asynchronous kernels on the caller's stream (the axis transpose of GridCreator._device_volume: 0.3 ms on a 256^3 map).  With
+    `wait()` right behind `start()` (create_grids_from_mrc; write_files="sync") the first gather used to be ordered behind NOTHING and
+    could cut a half-transposed volume.  The writer now waits for an event recorded on the caller's stream when it is started.  A
+    256^3 map, transposed ([z,y,x] -> [x,y,z]), joined at once: every one of the 216 tile files against the numpy tiler; then the
+    same through the wrapper in "sync" mode with the map handed over on the GPU (no file read between the producer and the cut)."""
+    from mica_amd import handoff, mrc
+    from mica_amd.create_grids import GridCreator
+    from mica_amd.synth import synth_map_fast
+    N = 256
+    raw = synth_map_fast(N, 77)
+    mp = str(tmp_path / "map.mrc")
+    mrc.write_mrc(mp, raw, stats=(0.0, 1.0, 0.5, 0.3))
+    vol, _ = vo.transpose_axes(raw, 1, 2, 3, [0, 0, 0])
+    ref, idx = vo.tile_volume(np.ascontiguousarray(vol), 48, 8)
+    want = {f"i{i}_j{j}_k{k}": sha(ref[t]) for t, (i, j, k, _, _, _) in enumerate(idx)}
+    del ref
+
+    def check(d, prefix):
+        files = sorted(glob.glob(os.path.join(d, "*.npz")))
+        assert len(files) == len(want) == 216 and not glob.glob(os.path.join(d, ".*"))      # no temporary name left behind
+        for f in files:
+            key = os.path.basename(f)[len(prefix) + 1:-4]
+            assert sha(np.load(f)["grid"]) == want[key], f
+
+    gc = GridCreator(quiet=True, engine=eng)
+    for rep in range(2):                                   # the second pass finds the pinned staging buffers cached: the tightest timing
+        d = str(tmp_path / f"direct{rep}")
+        n, off = gc.create_grids_from_mrc(mp, d, file_prefix="grid")
+        assert n == 216 and off == [0.0, 0.0, 0.0]
+        check(d, "grid")
+    # the wrapper, volume handed over on the GPU by the stage that "wrote" the MRC: register it as DataPreprocessor does
+    t = torch.from_numpy(raw).cuda()
+    _, hd = mrc.read_mrc(mp)
+    handoff.register_file(mp, t, hd)
+    d = str(tmp_path / "grids" / "normalized_map_grids")
+    res = gc.create_normalized_map_grids(mp, d)
+    assert res["success"] and res["grid_count"] == 216
+    check(d, "normalized_map_grid")
     handoff.clear()
 
 
