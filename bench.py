@@ -42,28 +42,31 @@ def host_threads():
     return max(1, min(n, 16))       # a one-GPU box's CPU share is 16
 
 
-def cpu_baseline(weights, tiles_map, tiles_af, vol_host):
+def cpu_baseline(weights, tiles_map, tiles_af, vol_host, keep=None):
     """The CPU oracle (torch CPU fp32 = the reference CPU path's arithmetic; validated bit-exact against the reference
     module in the build container) timed on this host per BASELINE.md section 4: one warm-up tile, then timed tiles of
     the same synthetic map, AF path, batch 1, at all usable cores and at 8 threads; plus the numpy tiler / stitch /
-    normaliser on the same map."""
+    normaliser on the same map.  `keep` (a dict) receives the oracle's logits of the timed tiles {tile index: (bb, ca, aa)}:
+    the checker's outputs, compared with the GPU's records of the same tiles outside this function (`parity`)."""
     import numpy as np
     import torch
     from oracle import model_oracle as mo   # cpu_baseline leg only
     from oracle import volume_oracle as vo
 
-    def run(threads, idxs):
+    def run(threads, idxs, keep=None):
         torch.set_num_threads(threads)
         ts = []
         for i in idxs:
             t0 = time.perf_counter()
-            mo.mica_forward(weights, tiles_map[i:i + 1], tiles_af[i:i + 1])
+            o = mo.mica_forward(weights, tiles_map[i:i + 1], tiles_af[i:i + 1])
             ts.append(time.perf_counter() - t0)
+            if keep is not None:
+                keep[i] = tuple(t.numpy() for t in o)
         return ts
 
     k = host_threads()
     run(k, [0])                                          # warm-up (untimed)
-    full = run(k, [1, 2, 3])
+    full = run(k, [1, 2, 3], keep)
     out = {"value": len(full) / sum(full), "unit": "sub-grids/s", "cores": k, "kind": "port",
            "sample": "3 timed 64^3 tiles (after 1 warm-up) of the same synthetic map, AF path, batch 1, torch CPU fp32, "
                      "%.1f s; a whole 4096-tile map is extrapolated linearly (tiles are independent and equal cost)" % sum(full),
@@ -164,6 +167,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-tiling", action="store_true")
     ap.add_argument("--no-whole-map", action="store_true")
+    ap.add_argument("--af-coverage", type=float, default=0.3,
+                    help="N=1: also time the same map with atoms in a centred ball holding this fraction of the box only (a docked model covers "
+                         "part of the map; tiles outside take the zero-AF branch, batches mix both) -> `mixed_af`; 0 = skip")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--force-exchange", action="store_true",
@@ -375,6 +381,44 @@ def main():
         del vols, norm
         out = torch.zeros((23, n, n, n), dtype=torch.float32, device=dev)
 
+    # the same map with atoms in part of the box only: a centred ball holding `--af-coverage` of the volume.  z is the fastest tile
+    # index, so batches of consecutive tiles cross the ball's surface and mix the two input branches (models/model.py:56-74).  Since
+    # round 6 only MultiScaleInput runs per branch; encoders, FPN and heads run once per batch (forward.hip::trunk).
+    mixed = None
+    if rank == 0 and world == 1 and af is not None and args.af_coverage > 0:
+        rr = (args.af_coverage * 3.0 / (4.0 * np.pi)) ** (1.0 / 3.0) * n
+        ax = (torch.arange(n, device=dev, dtype=torch.float32) - (n - 1) / 2.0) ** 2
+        ball = (ax[:, None, None] + ax[None, :, None] + ax[None, None, :]) <= rr * rr
+        afm = af * ball.to(af.dtype)
+        cover = float(ball.float().mean())
+        del ball
+        ks = 40
+        sel = [int(round(q * (nb - 1) / (ks - 1))) * B for q in range(ks)]           # batches spread evenly over the whole map
+        runs, with_atoms = 0, 0
+
+        def stepm(f, count=False):
+            nonlocal runs, with_atoms
+            eng.stitch_tiles(vp.run_batch(vol, afm, f, B), out, g3, p, f)
+            if count:
+                runs += eng.last_input_runs
+                with_atoms += eng.last_af_tiles
+        stepm(sel[0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for f in sel:
+            stepm(f)
+        torch.cuda.synchronize()
+        dm = time.perf_counter() - t1
+        for f in sel:                       # untimed second pass: how the batches were cut
+            stepm(f, True)
+        torch.cuda.synchronize()
+        mixed = {"af_coverage": cover, "value": ks * B / dm, "unit": "sub-grids/s", "steps": ks, "ratio_to_value": ks * B / dm / value,
+                 "tiles_with_atoms": with_atoms / (ks * B), "input_runs_per_batch": runs / ks,
+                 "note": "same map and tiling as `value`, atoms only inside a centred ball of that volume share; 40 batches spread evenly over "
+                         "the map; input_runs_per_batch = runs of consecutive tiles with equal AF3 gate per batch (MultiScaleInput launches per "
+                         "run; the rest of the network once per batch)"}
+        del afm
+
     # rooflines: HIP events (on the launch stream, inside the library) around every dense-conv and every depthwise
     # conv3d launch of one extra, untimed batch.  PMC traffic comes from the committed rocprofv3 passes (profiles/).
     roof = hbm = None
@@ -453,13 +497,29 @@ def main():
                "traffic": traffic.get("depthwise_kernel", {}).get("hbm_bytes"), "launches_per_batch": dl,
                "avg_launch_ms": dms / max(dl, 1), "algorithmic_bytes_per_launch": dbytes / max(dl, 1),
                "note": "BASELINE metric's 'HBM GB/s on conv3d': algorithmic 8 B per voxel and channel / HIP-event time"}
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
         first = (T // 2 // 4) * 4
         tm = eng.gather_tiles(vol, g3, p, first, 4).cpu().view(4, 1, S, S, S)
         ta = eng.gather_tiles(af, g3, p, first, 4).cpu() if af is not None else torch.zeros((4, 24, S, S, S))
+        # the GPU's logits of the tiles the CPU leg is about to compute, EVERY voxel (the checker's outputs used as a checker)
+        from mica_amd.engine import AF_PER_TILE
+        gl = [t.cpu().numpy() for t in eng.forward_logits(tm.to(dev), ta.to(dev), AF_PER_TILE)]
         del out
-        cpu = cpu_baseline(weights, tm, ta, vol_host)
+        kept = {}
+        cpu = cpu_baseline(weights, tm, ta, vol_host, kept)
+
+        def scaled(a, b):
+            a, b = a.astype(np.float64), b.astype(np.float64)
+            e = np.abs(a - b) / np.maximum(np.abs(b), np.sqrt(np.mean(b * b)))
+            return float(e.max()), float(np.sqrt(np.mean(e * e)))
+        per = [[scaled(gl[h][i:i + 1], kept[i][h]) for h in range(3)] for i in sorted(kept)]
+        parity = {"tiles": len(per), "voxels_per_tile": int(S ** 3), "logits_compared": int(len(per) * 29 * S ** 3),
+                  "max_scaled": [max(t[h][0] for t in per) for h in range(3)], "rms_scaled": [float(np.sqrt(np.mean([t[h][1] ** 2 for t in per]))) for h in range(3)],
+                  "heads": ["backbone", "carbon_alpha", "amino_acid"],
+                  "against": "oracle/model_oracle.py (torch CPU float32 = the reference CPU path's arithmetic, bit-equal to the reference module) on "
+                             "every logit of the 64^3 tiles the cpu_baseline leg times; metric max / rms of |gpu - ref| / max(|ref|, rms(ref)); "
+                             "the reference's own float32 runs differ from each other by up to 1.06e-4 in this metric (tests/golden/manifest.json S64)"}
     if rank == 0:
         emit({
             "metric": "64^3 sub-grids/sec", "value": value, "unit": "sub-grids/s", "n_gpus": world, "steps": args.steps,
@@ -479,7 +539,7 @@ def main():
                 "value": whole["value"], "unit": "sub-grids/s", "seconds": whole["predict_seconds"], "tiles": whole["tiles"],
                 "note": "ONE complete map, every window of the reference tiling (48, 8), wall clock: what the power-bound kernel mix holds "
                         "over a whole map; `value` above is the contract's K timed steps (a ~2-s window, typically 2-3 % higher)"},
-            "alt_tiling": alt, "whole_map": whole, "roofline": roof, "hbm_conv3d": hbm, "cpu_baseline": cpu})
+            "alt_tiling": alt, "whole_map": whole, "mixed_af": mixed, "parity": parity, "roofline": roof, "hbm_conv3d": hbm, "cpu_baseline": cpu})
     if grouped:
         dist.barrier()                          # rank 0 ran the extra profiled batch: leave together
         dist.destroy_process_group()

@@ -284,6 +284,11 @@ int mica_op_stem(mica_ctx* ctx, const float* d_map, int batch, int d, int h, int
 float mica_get_activation_scale(const mica_ctx* ctx);
 float mica_get_last_forward_scale(const mica_ctx* ctx);
 int mica_get_last_forward_retries(const mica_ctx* ctx);     /* tiles of the last mica_forward_* call that were repeated at a lower scale */
+/* Runs of consecutive tiles with equal AF3 gate the last forward pass cut its batch into.  Only MultiScaleInput (model.py:43-74) is
+ * launched per run - it is the one stage in which a tile with atoms and one without differ (:56-63 against :69-74); encoders, FPN and
+ * heads run ONCE per call for the whole batch whatever the mix (ABI 3; until ABI 2 the whole network ran once per run).          */
+int mica_get_last_forward_input_runs(const mica_ctx* ctx);
+int mica_get_last_forward_af_tiles(const mica_ctx* ctx);    /* tiles of that pass that took the AF3 branch (feat_conv / fusion) */
 int mica_set_activation_scale(mica_ctx* ctx, float scale);
 
 /* ---- introspection for bench.py ----------------------------------------------------------- */

@@ -28,6 +28,10 @@ def main(argv=None) -> int:
     ap.add_argument("--batch", type=int, default=8, help="tiles per forward call")
     ap.add_argument("--grid-size", type=int, default=48)
     ap.add_argument("--padding", type=int, default=8)
+    ap.add_argument("--gpus", type=int, default=None, help="shard the tiles over this many GPUs of the node (default: MICA_GPUS, else 1): this process "
+                    "is rank 0, the others are child processes it starts (mica_amd/multi.py)")
+    ap.add_argument("--rank-backend", default=None, help="nccl (= RCCL over xGMI, default) | gloo (rehearsal of N > 1 on one card, host-staged)")
+    ap.add_argument("--rank-devices", default=None, help="comma-separated device index per rank (default 0 .. gpus-1)")
     args = ap.parse_args(argv)
 
     from . import mrc
@@ -36,6 +40,12 @@ def main(argv=None) -> int:
     from .preprocessing import DataPreprocessor
     from .weights import load_checkpoint_state_dict
 
+    from . import multi
+    gpus = multi.configured_gpus(args.gpus)
+    pool = None
+    if gpus > 1:            # the workers start first: their import and workspace allocation run beside this rank's own start-up and normaliser
+        pool = multi.get_pool(gpus, tile=args.grid_size + 2 * args.padding, batch=args.batch, backend=args.rank_backend,
+                              devices=None if args.rank_devices is None else [int(v) for v in args.rank_devices.split(",")]).spawn()
     t0 = time.time()
     eng = Engine(args.device, max_batch=args.batch, tile_size=args.grid_size + 2 * args.padding)
     eng.load_state_dict(load_checkpoint_state_dict(args.model))
@@ -53,7 +63,13 @@ def main(argv=None) -> int:
         enc = dp.encode_AF3_volume(args.docked_model, hd.origin, norm.shape)            # [24, nz, ny, nx] on the device
         perm = _axis_perm(hdn)
         d_af = enc.permute(0, *[1 + p for p in perm]).contiguous()
-    vols = VolumePredictor(eng, args.grid_size, args.padding, args.batch).predict_volume(d_vol, d_af, to_host=True)
+    if pool is not None:
+        runner = multi.EngineRunner(None, eng.tile_size, args.batch, engine=eng, loaded_model=args.model)
+        vols = pool.predict(runner, args.model, d_vol, None if d_af is None else d_af.to(torch.uint8), args.grid_size, args.padding, to_host=True)
+        print(pool.startup_report())
+        pool.close()
+    else:
+        vols = VolumePredictor(eng, args.grid_size, args.padding, args.batch).predict_volume(d_vol, d_af, to_host=True)
     os.makedirs(args.out, exist_ok=True)
     for k, v in vols.items():
         np.save(os.path.join(args.out, f"{k}.npy"), v)

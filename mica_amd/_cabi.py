@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmica_hip.so")
 
-ABI_VERSION = 2          # mica_abi_version() of the library these signatures describe (bumped whenever an export or a struct changes)
+ABI_VERSION = 3          # mica_abi_version() of the library these signatures describe (bumped whenever an export or a struct changes)
 MICA_OK = 0
 MICA_ERR_ARG, MICA_ERR_HIP, MICA_ERR_STATE, MICA_ERR_RANGE = -1, -2, -3, -4
 AF_NONE, AF_PER_TILE, AF_BATCH, AF_ALWAYS = 0, 1, 2, 3
@@ -65,6 +65,8 @@ SIGNATURES = {
     "mica_get_activation_scale": (_F, [_P]),
     "mica_get_last_forward_scale": (_F, [_P]),
     "mica_get_last_forward_retries": (_I, [_P]),
+    "mica_get_last_forward_input_runs": (_I, [_P]),
+    "mica_get_last_forward_af_tiles": (_I, [_P]),
     "mica_set_activation_scale": (_I, [_P, _F]),
     "mica_set_profiling": (_I, [_P, _I]),
     "mica_get_conv_profile": (_I, [_P, _DP, _LP, _DP]),

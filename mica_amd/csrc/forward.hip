@@ -106,6 +106,8 @@ struct mica_ctx {
                                      // heads' conv1 x3) on its 64-channel variant
     float last_scale = ASCALE_DEFAULT;   // the lowest scale a tile of the last forward call needed (forward_checked)
     int last_retries = 0;                // tiles of the last forward call that had to be repeated at a lower scale
+    int last_input_runs = 0;             // runs of equal AF3 gate the last forward_impl cut its batch into (MultiScaleInput launches)
+    bool trunk_per_run = false;          // A/B switch (MICA_TRUNK_PER_RUN=1): the whole network once per run, as rounds 1-5 did
     std::vector<char> use_af;        // per tile of the last forward_impl call: AF3 branch taken
     float* h_abs = nullptr;       // pinned
     int* h_err = nullptr;         // pinned
@@ -380,27 +382,39 @@ void run_stem(mica_ctx* c, const float* d_map, int B, Dims d, SplitView out, flo
     launch_stem(d_map, B, d, c->stem_w, c->stem_b, out, out_raw, gap, c->ws, enc, st);
 }
 
-// One run of tiles that share the AF branch (model.py:56-74).  Workspace slots 0..B-1.
-int forward_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool use_af, float* o_bb, float* o_ca,
-                float* o_aa, hipStream_t st, int slot0) {
+// MultiScaleInput (model.py:43-74) for ONE run of B consecutive tiles that take the same branch - the only part of the network in
+// which a tile with AF3 atoms and one without differ (model.py:56-63 against :69-74).  Every buffer it touches is scratch at slots
+// 0 .. B-1 (the runs of a call follow each other on the stream), except its result: x0 of the run lands at slots slot0 .. slot0+B-1
+// of S_x0, where `trunk` finds the whole batch, and the range flags are the tiles' own (d_err + err0).
+void input_run(mica_ctx* c, const float* d_map, const float* d_af, int B, bool use_af, hipStream_t st, int slot0, int err0) {
     const int V = c->V;
     const Dims d = c->d;
-    SplitView none{nullptr, 0, 0, 0};
-    c->cur_err = c->d_err + slot0;
-    // ---- MultiScaleInput (model.py:43-74) ------------------------------------------------------
+    c->cur_err = c->d_err + err0;
+    // S_x0 is a Winograd F(2,3) operand [B][4 chunks][4 p][4 q][Vh][8] (encoder.0 never runs on the F(4,3) kernel)
+    const int64_t x0_tile = (int64_t)4 * 16 * ((int64_t)d.D * d.H * ((d.W + 1) / 2)) * 8;
+    const SplitView x0 = view(c->S_x0 + (int64_t)slot0 * x0_tile, 4, 0, 4);
     run_stem(c, d_map, B, d, view(c->S_exp, 8, 0, 8), nullptr, c->v_pool, SplitEnc{c->cur_err, c->ascale}, st);
     if (!use_af) {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->downsizing.d_cin_scale, 128, st);
-        run_conv1x1(c, c->downsizing, split_src(c->S_exp, 8, 0, 8), nullptr, view(c->S_x0, 4, 0, 4), c->R_a, B, st);
+        run_conv1x1(c, c->downsizing, split_src(c->S_exp, 8, 0, 8), nullptr, x0, c->R_a, B, st);
     } else {
         gate(c, c->exp_att, c->v_pool, nullptr, B, nullptr, nullptr, c->fusion0.d_cin_scale, 192, st);
         launch_prep_ncdhw_wino(d_af, B, d, 24, view(c->S_af, 2, 0, 2), SplitEnc{c->cur_err, c->ascale}, st);
         run_conv(c, c->feat_conv, SrcList().add(c->S_af, 2, 0, 2), c->R_b, B, st);
         launch_feat_gate(c->R_b, B, V, c->fg_w0, c->fg_b0, c->fg_w2, c->fg_b2, view(c->S_fw, 4, 0, 4), SplitEnc{c->cur_err, c->ascale}, st);
         const Conv1Src fw = split_src(c->S_fw, 4, 0, 4);
-        run_conv1x1(c, c->fusion0, split_src(c->S_exp, 8, 0, 8), &fw, view(c->S_x0, 4, 0, 4), c->R_a, B, st);
+        run_conv1x1(c, c->fusion0, split_src(c->S_exp, 8, 0, 8), &fw, x0, c->R_a, B, st);
     }
+}
 
+// Everything behind MultiScaleInput - encoders, FPN, heads (model.py:336-346) - ONCE for all B tiles of the call, whatever mix of
+// branches produced their x0 (round 6; until round 5 the whole network ran once per run of equal gates, i.e. 2-4 small forwards per
+// batch on a map whose docked model covers part of the box).  Workspace slots 0..B-1.
+int trunk(mica_ctx* c, int B, float* o_bb, float* o_ca, float* o_aa, hipStream_t st, int slot0 = 0) {
+    const int V = c->V;
+    const Dims d = c->d;
+    SplitView none{nullptr, 0, 0, 0};
+    c->cur_err = c->d_err + slot0;
     // ---- encoders (model.py:149-152) -----------------------------------------------------------
     const _Float16* X = c->S_x0;
     for (int e = 0; e < 3; ++e) {
@@ -506,13 +520,22 @@ int forward_impl(mica_ctx* c, const float* d_map, const float* d_af, int B, int 
         }
     }
     c->use_af = use;
-    for (int b0 = 0; b0 < B;) {
+    c->last_input_runs = 0;
+    for (int b0 = 0; b0 < B;) {                      // MultiScaleInput per run of tiles with equal gate, into their slots of x0
         int b1 = b0 + 1;
         while (b1 < B && use[b1] == use[b0]) ++b1;
-        int r = forward_run(c, d_map + (int64_t)b0 * V, d_af ? d_af + (int64_t)b0 * 24 * V : nullptr, b1 - b0, use[b0] != 0,
-                            o_bb + (int64_t)b0 * 4 * V, o_ca + (int64_t)b0 * 4 * V, o_aa + (int64_t)b0 * 21 * V, st, b0);
-        if (r) return r;
+        const bool whole_net = c->trunk_per_run;     // A/B switch: rounds 1-5 ran the whole network once per run (workspace slots 0 .. n-1)
+        input_run(c, d_map + (int64_t)b0 * V, d_af ? d_af + (int64_t)b0 * 24 * V : nullptr, b1 - b0, use[b0] != 0, st, whole_net ? 0 : b0, b0);
+        if (whole_net) {
+            int r = trunk(c, b1 - b0, o_bb + (int64_t)b0 * 4 * V, o_ca + (int64_t)b0 * 4 * V, o_aa + (int64_t)b0 * 21 * V, st, b0);
+            if (r) return r;
+        }
+        ++c->last_input_runs;
         b0 = b1;
+    }
+    if (!c->trunk_per_run) {                         // ... and the rest of the network once for the whole batch
+        int r = trunk(c, B, o_bb, o_ca, o_aa, st);
+        if (r) return r;
     }
     CHECK_LAUNCHES(c);
     if (c->profiling) {
@@ -608,7 +631,7 @@ static int forward_checked(mica_ctx* c, const float* d_map, const float* d_af, i
 // =================================================================================================
 extern "C" {
 
-int mica_abi_version(void) { return 2; }
+int mica_abi_version(void) { return 3; }
 
 const char* mica_last_error(const mica_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -641,6 +664,7 @@ int mica_create_dims(int device, int max_batch, int td, int th, int tw, mica_ctx
     mica_ctx* c = new mica_ctx();
     if (const char* ev = getenv("MICA_STEM_MFMA")) c->stem_mode = atoi(ev) != 0;
     if (const char* ev = getenv("MICA_RAW_CBLK")) c->raw_cblk = atoi(ev) == 32 ? 32 : 0;
+    if (const char* ev = getenv("MICA_TRUNK_PER_RUN")) c->trunk_per_run = atoi(ev) != 0;
     if (const char* ev = getenv("MICA_F43")) { const int m = atoi(ev); c->f43_mode = m < 0 || m > 3 ? 3 : m; }      // A/B switch (0: the F(2,3) kernel everywhere)
     c->device = device;
     c->maxB = max_batch;
@@ -1351,6 +1375,14 @@ int mica_op_stem(mica_ctx* c, const float* d_map, int batch, int d, int h, int w
 
 float mica_get_activation_scale(const mica_ctx* c) { return c ? c->ascale : 0.f; }
 int mica_get_last_forward_retries(const mica_ctx* c) { return c ? c->last_retries : 0; }
+
+int mica_get_last_forward_input_runs(const mica_ctx* c) { return c ? c->last_input_runs : 0; }
+
+int mica_get_last_forward_af_tiles(const mica_ctx* c) {
+    int n = 0;
+    if (c) for (char u : c->use_af) n += u != 0;
+    return n;
+}
 
 float mica_get_last_forward_scale(const mica_ctx* c) { return c ? c->last_scale : 0.f; }
 

@@ -63,6 +63,8 @@ class Engine:
         self.weights_loaded = False
         self.last_forward_scale = 16.0     # lowest activation scale any chunk of the last forward_* call needed
         self.forward_retries = 0           # tiles of the last forward_* call that were repeated at a lower activation scale
+        self.last_input_runs = 0           # runs of equal AF3 gate its last library call was cut into (MultiScaleInput launches per run)
+        self.last_af_tiles = 0
 
     # -- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -112,6 +114,8 @@ class Engine:
         self._check(r, what)
         sc = float(self.lib.mica_get_last_forward_scale(self._h))
         self.forward_retries += int(self.lib.mica_get_last_forward_retries(self._h))
+        self.last_input_runs = int(self.lib.mica_get_last_forward_input_runs(self._h))      # of the last library call of this forward
+        self.last_af_tiles = int(self.lib.mica_get_last_forward_af_tiles(self._h))          # its tiles that took the AF3 branch
         self.last_forward_scale = min(self.last_forward_scale, sc)
         if sc < self.LOW_SCALE_WARN:
             import warnings

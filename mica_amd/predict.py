@@ -23,8 +23,14 @@ KEYS = ("backbone_probability", "carbon_alpha_probability", "amino_acid_predicti
 
 class CryoEMPredictor:
     def __init__(self, model_path, grids_path, output_path, save_output=True, device="cuda", quiet=False, batch_size=8,
-                 reference_batching=False):
-        """Same positional arguments as the reference (utils/predict.py:48).  Two additions:
+                 reference_batching=False, gpus=None):
+        """Same positional arguments as the reference (utils/predict.py:48).  Three additions:
+        `gpus` - (default: the environment's MICA_GPUS, else 1) shard the tiles of the map over that many GPUs of the node
+        (BASELINE.json configs[2]): this process is rank 0, ranks 1 .. N-1 are persistent child processes that mica_amd/multi.py starts
+        (once, kept for the next map, gone with the process); the volumes GridCreator left on this GPU are broadcast to them over
+        RCCL, every rank runs its share of the tile batches and the cropped records come back to this rank, which stitches.  The
+        volumes are bit-identical to gpus=1.  Applies to the resident route (the tiler ran in this process); the tile-file route
+        reads its files in one process and stays on one GPU;
         `batch_size` - tiles per forward call (results do not depend on it with per-tile gating);
         `reference_batching` - reproduce the reference's batching exactly (utils/predict.py:176-215, 278-286): batch 1
         up to `batch_threshold` tiles (= per-tile AF3 gating), above it batches of `optimal_batch_size` (at most 8) tiles in
@@ -46,6 +52,12 @@ class CryoEMPredictor:
         self.optimal_batch_size = 1
         self.use_resident_volumes = True    # take the volumes a GridCreator of this process left on the GPU (handoff.py) instead of its files
         self.keep_resident_volumes = False  # True: leave them registered after the prediction (a second predictor on the same grids_path)
+        from .multi import configured_gpus
+        self.gpus = configured_gpus(gpus)
+        self.rank_backend = None            # None: MICA_RANK_BACKEND, else "nccl" (= RCCL over xGMI); "gloo" rehearses N > 1 on one card
+        self.rank_devices = None            # None: MICA_RANK_DEVICES, else 0 .. gpus-1 (rank 0's entry should be this predictor's device)
+        self.gather_to_root = False         # records to the stitching rank alone (dist.gather) instead of the all-gather north_star names
+        self.rank_pool = None               # the pool of the last multi-GPU run (its start-up report: profiles/r06_rank_startup.txt)
         self.resident = None                # (map entry, AF3 entry or None) once select_processing_strategy found them
         self.engine = None
         self.sample_count = 0
@@ -259,7 +271,15 @@ class CryoEMPredictor:
                 if ent is not None and ent.writer is not None:
                     ent.writer.release()
             af = a.volume if a is not None and len(a.channels) == 24 else None
-            vols = VolumePredictor(self.engine, m.grid_size, m.padding, self.engine.max_batch).predict_volume(m.volume, af, to_host=True)
+            if self.gpus > 1:
+                from . import multi
+                self.rank_pool = pool = multi.get_pool(self.gpus, tile=self.engine.tile_size, batch=self.engine.max_batch, backend=self.rank_backend,
+                                                       devices=self.rank_devices, conv_variant=None)
+                runner = multi.EngineRunner(None, self.engine.tile_size, self.engine.max_batch, engine=self.engine, loaded_model=self.model_path)
+                vols = pool.predict(runner, self.model_path, m.volume, af, m.grid_size, m.padding, gather_to_root=self.gather_to_root, to_host=True)
+                self.engine = runner.engine
+            else:
+                vols = VolumePredictor(self.engine, m.grid_size, m.padding, self.engine.max_batch).predict_volume(m.volume, af, to_host=True)
             self.timing_stats['inference'] = time.time() - t0
             return vols
         except Exception as e:
@@ -267,11 +287,25 @@ class CryoEMPredictor:
             self.timing_stats['inference'] = time.time() - t0
             return None
 
+    @staticmethod
+    def close_ranks():
+        """End the worker processes of `gpus` > 1 now (they otherwise stay for the next map and leave at interpreter exit)."""
+        from . import multi
+        multi.shutdown()
+
     def run_prediction(self):
         t0 = time.time()
         try:
             if not self.select_processing_strategy():
                 return False, {}
+            if self.gpus > 1 and self.resident is not None:
+                # the workers' python + torch import and 37-GB workspaces come up beside this rank's weight load (if the Solver-flow
+                # shim has not started them already, beside the whole of getData)
+                from . import multi
+                multi.get_pool(self.gpus, tile=self.resident[0].grid_size + 2 * self.resident[0].padding, batch=self.batch_size,
+                               backend=self.rank_backend, devices=self.rank_devices, conv_variant=None).spawn()
+            elif self.gpus > 1:
+                self.logger.warning("gpus > 1 applies to volumes the tiler of this process left on the GPU; the tile-file route runs on one GPU")
             if not self.load_model():
                 return False, {}
             if self.resident is not None:

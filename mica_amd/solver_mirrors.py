@@ -29,6 +29,10 @@ from . import preprocessing as _pp
 class DataPreprocessor(_pp.DataPreprocessor):
     def __init__(self, map_path, AF3_results, quiet=False, engine=None, device=0, write_files="background"):
         super().__init__(map_path, AF3_results, quiet, engine=engine, device=device, write_files=write_files)
+        # getData begins here (utils/modeler.py:675): with MICA_GPUS > 1 the worker ranks start NOW, so that their python + torch import
+        # and their engines' workspaces come up beside the normaliser and the tilers, not in front of the first tile
+        from . import multi
+        multi.prestart()
 
 
 class GridCreator(_cg.GridCreator):

@@ -590,6 +590,82 @@ def test_file_modes_of_the_mirrors_and_of_the_solver_shim(monkeypatch):
     assert solver_mirrors.CryoEMPredictor is CryoEMPredictor
 
 
+def _fake_pool(**kw):
+    from mica_amd.multi import RankPool
+    return RankPool(2, tile=16, batch=2, backend="gloo", devices=[0, 0], runner="tests.multi_fake:FakeRunner", timeout_s=60, **kw)
+
+
+def test_rank_pool_two_ranks_persistent_workers_and_clean_shutdown(tmp_path):
+    """mica_amd/multi.py (BASELINE configs[2] behind the single-process call site, reference utils/modeler.py:722-738): rank 0 is the
+    calling process, rank 1 a fresh child that stays for the next map.  Two maps through one pool over gloo with the stand-in runner:
+    the sharded result equals the expected volume, the child is the same process for both maps, loads the 'checkpoint' once, reports its
+    start-up marks, and has exited with code 0 when close() returns."""
+    from tests.multi_fake import FakeRunner
+    ck = tmp_path / "ckpt.txt"
+    ck.write_text("3.0")
+    pool = _fake_pool().spawn()
+    try:
+        child = pool.procs[0]
+        r0 = FakeRunner(0, 16, 2)
+        for n, shape in enumerate(((20, 9, 17), (33, 16, 5))):
+            vol = torch.arange(int(np.prod(shape)), dtype=torch.float32).reshape(shape) / 7.0
+            af = (torch.arange(24 * int(np.prod(shape))).reshape(24, *shape) % 11 == 0).to(torch.uint8) if n else None
+            out = pool.predict(r0, str(ck), vol, af, grid=8, pad=0, gather_to_root=bool(n))
+            want = vol * 3.0 + (0.0 if af is None else float(af.sum()))
+            assert np.array_equal(out["volume"], want.numpy())
+            assert pool.procs[0] is child and child.poll() is None and pool.maps == n + 1
+        assert len(pool.startup) == 1 and pool.startup[0]["rank"] == 1
+        s = pool.startup[0]
+        assert s["spawned"] <= s["imported"] <= s["engine"] <= s["joined"] <= s["first_map_done"]
+        assert [st["rank"] for st in pool.last_status] == [0, 1] and all(st["ok"] for st in pool.last_status)
+        assert "rank 1: python + torch import" in pool.startup_report()
+    finally:
+        pool.close()
+    assert child.returncode == 0 and pool.procs == [] and not torch.distributed.is_initialized()
+    pool.close()                                                            # idempotent
+    with pytest.raises(Exception, match="closed"):
+        pool.predict(r0, str(ck), torch.zeros(8, 8, 8), None, 8, 0)
+
+
+@pytest.mark.parametrize("where", ["init", "load", "predict", "killed"])
+def test_rank_pool_worker_failures_end_loudly_and_leave_no_process(tmp_path, monkeypatch, where):
+    """A worker that cannot start (its runner raises), cannot load the checkpoint, fails inside the map or was killed between two maps
+    takes the call down with an exception that names the rank - within seconds, not at a collective's time-out - and the pool is closed:
+    every child has been joined (or killed by its exact PID) when the exception reaches the caller."""
+    import time
+    from mica_amd.engine import MicaHipError
+    from tests.multi_fake import FakeRunner
+    ck = tmp_path / "ckpt.txt"
+    ck.write_text("2.0")
+    if where != "killed":
+        monkeypatch.setenv("MICA_FAKE_FAIL", f"{where}:1")
+    pool = _fake_pool().spawn()
+    child = pool.procs[0]
+    r0 = FakeRunner(0, 16, 2)
+    vol = torch.ones(16, 16, 16)
+    t0 = time.time()
+    try:
+        if where == "killed":
+            assert np.array_equal(pool.predict(r0, str(ck), vol, None, 8, 0)["volume"], 2.0 * vol.numpy())
+            child.kill()
+            child.wait()
+            with pytest.raises(MicaHipError, match=r"rank\(s\) \[\(1, -9\)\] have exited"):
+                pool.predict(r0, str(ck), vol, None, 8, 0)
+        elif where == "init":
+            with pytest.raises(MicaHipError, match="exited during start-up"):
+                pool.predict(r0, str(ck), vol, None, 8, 0)
+        elif where == "load":
+            with pytest.raises(MicaHipError, match="rank 1: FileNotFoundError: injected"):
+                pool.predict(r0, str(ck), vol, None, 8, 0)
+        else:
+            with pytest.raises(Exception):
+                pool.predict(r0, str(ck), vol, None, 8, 0)
+    finally:
+        pool.close()
+    assert time.time() - t0 < 45 and pool.closed and pool.procs == [] and child.poll() is not None
+    assert not torch.distributed.is_initialized()
+
+
 def test_engine_methods_run_under_the_engines_lock():
     """A context is not thread-safe (include/mica_hip.h) and the tile-file writer shares the tiler's engine from its own thread:
     every public Engine method takes the engine's re-entrant lock (mica_amd/engine.py)."""

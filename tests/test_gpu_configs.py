@@ -190,6 +190,99 @@ def test_training_tilers_create_and_save_grids(tmp_path, eng):
     assert gc.create_and_save_grids(str(tmp_path / "missing.mrc"), str(tmp_path / "x")) == 0
 
 
+def test_config2_through_the_product_entry_two_ranks_on_one_gpu(tmp_path, weights):
+    """BASELINE configs[2] behind the boundary the reference calls: ONE process builds `CryoEMPredictor(...)` and calls
+    `run_prediction()` (utils/modeler.py:722-738).  `gpus=2`: this process is rank 0, rank 1 is a fresh child that
+    mica_amd/multi.py starts; the volumes GridCreator left on the GPU are broadcast to it, both run their share of the tile batches,
+    rank 0 stitches.  Both ranks on the one GPU of this box over gloo (host-staged broadcast and exchange - RCCL refuses two ranks
+    on one device): the four volumes equal the single-rank ones bit for bit; a second map goes through the SAME worker process; a
+    missing checkpoint fails loudly on every rank and leaves no process behind.  Then the RCCL branch in the only form one GPU
+    allows: a pool of ONE rank with the collective forced, initialised AFTER this process has used the GPU (which rank 0 of a real
+    node always has: the tiler ran in it)."""
+    from mica_amd import handoff, mrc, multi
+    from mica_amd.create_grids import GridCreator
+    from mica_amd.predict import CryoEMPredictor
+
+    ck = str(tmp_path / "ckpt.pth")
+    _save_ckpt(ck, weights)
+
+    def get_data(tag, shape, seed):
+        inp = tmp_path / tag
+        os.makedirs(inp / "AF3_encodings")
+        raw = synth_density(shape, seed)
+        mp = str(inp / "resampled_normalized_map.mrc")
+        mrc.write_mrc(mp, raw, nxstart=1, nystart=2, nzstart=3)
+        enc = synth_af(shape, seed, 2e-3)
+        enc[:, :, :, : shape[2] // 2] = 0                       # tiles without atoms: per-tile gating on both ranks
+        from mica_amd.af3_encoding import CHANNEL_NAMES
+        for c, name in enumerate(CHANNEL_NAMES):
+            mrc.write_mrc(str(inp / "AF3_encodings" / f"{name}_encoding.mrc"), enc[c], nxstart=1, nystart=2, nzstart=3)
+        grids = str(inp / "grids")
+        gc = GridCreator(quiet=True, write_files=False)
+        assert gc.create_normalized_map_grids(mp, os.path.join(grids, "normalized_map_grids"))["success"]
+        assert gc.create_AF3_encodings_grids(str(inp / "AF3_encodings"), os.path.join(grids, "AF3_encoding_grids"))["success"]
+        return grids
+
+    def predict(grids, gpus, model=ck):
+        pred = CryoEMPredictor(model_path=model, grids_path=grids + "/", output_path=str(tmp_path / "out"), save_output=False, device="cuda",
+                               quiet=True, batch_size=2, gpus=gpus)
+        pred.rank_backend, pred.rank_devices = "gloo", [0, 0]
+        pred.keep_resident_volumes = True                      # the same resident volumes serve the one-rank and the two-rank run
+        ok, vols = pred.run_prediction()
+        assert (pred.resident is not None) or not ok
+        return ok, vols, pred
+
+    g1 = get_data("m1", (70, 50, 100), 91)                      # 2 x 2 x 3 = 12 tiles = 6 batches of 2: three rounds of two ranks
+    ok, ref1, _ = predict(g1, 1)
+    assert ok
+    ok, two1, p2 = predict(g1, 2)
+    assert ok and p2.rank_pool is not None and p2.rank_pool.maps == 1
+    worker = p2.rank_pool.procs[0]
+    for k in ref1:
+        assert np.array_equal(ref1[k], two1[k]), k
+    st = p2.rank_pool.last_status
+    assert [s["rank"] for s in st] == [0, 1] and st[0]["stats"]["collectives"] == 3 and st[0]["stats"]["world"] == 2
+    print(p2.rank_pool.startup_report())
+    # a second map of another shape: the same pool, the same worker process
+    g2 = get_data("m2", (50, 40, 100), 92)                      # 2 x 1 x 3 = 6 tiles = 3 batches: the last round has an idle rank
+    ok, ref2, _ = predict(g2, 1)
+    ok2, two2, p3 = predict(g2, 2)
+    assert ok and ok2 and p3.rank_pool is p2.rank_pool and p3.rank_pool.procs[0] is worker and worker.poll() is None and p3.rank_pool.maps == 2
+    for k in ref2:
+        assert np.array_equal(ref2[k], two2[k]), k
+    # failure: the checkpoint vanishes between the strategy step and the workers' load -> (False, {}), pool closed, worker gone
+    bad = str(tmp_path / "gone.pth")
+    _save_ckpt(bad, weights)
+    pred = CryoEMPredictor(model_path=bad, grids_path=g2 + "/", output_path=str(tmp_path / "out"), save_output=False, device="cuda", quiet=True,
+                           batch_size=2, gpus=2)
+    pred.rank_backend, pred.rank_devices, pred.keep_resident_volumes = "gloo", [0, 0], True
+    real_load = pred.load_model
+
+    def load_then_remove():
+        r = real_load()
+        os.remove(bad)
+        return r
+    pred.load_model = load_then_remove
+    assert pred.run_prediction() == (False, {})
+    assert worker.poll() is not None and p2.rank_pool.closed and not torch.distributed.is_initialized()
+    # the RCCL branch on one GPU: a group of one rank, collective forced, in a process that has long used the GPU
+    pool = multi.RankPool(1, tile=64, batch=2, backend="nccl", devices=[0], force_collective=True)
+    try:
+        pred = CryoEMPredictor(model_path=ck, grids_path=g2 + "/", output_path=str(tmp_path / "out"), save_output=False, device="cuda", quiet=True, batch_size=2)
+        assert pred.select_processing_strategy() and pred.load_model() and pred.resident is not None
+        m, a = pred.resident
+        runner = multi.EngineRunner(None, 64, 2, engine=pred.engine, loaded_model=ck)
+        vols = pool.predict(runner, ck, m.volume, a.volume, m.grid_size, m.padding, gather_to_root=False, to_host=True)
+        assert pool.last_status[0]["stats"]["backend"] == "nccl" and pool.last_status[0]["stats"]["collectives"] == 3       # 6 tiles / 2
+        for k in ref2:
+            assert np.array_equal(ref2[k], vols[k]), k
+        pred.engine.close()
+    finally:
+        pool.close()
+    assert not torch.distributed.is_initialized()
+    handoff.clear()
+
+
 def test_reference_batching_mode_vs_reference_golden(tmp_path, weights, golden_dir):
     """Row a18: the reference's >batch_threshold mode (utils/predict.py:176-215) tests the AF3 features of the whole batch
     (models/model.py:60).  Golden = the reference CryoEMPredictor with batch_threshold lowered to 1 on a 2-tile map whose

@@ -3,8 +3,12 @@
     GridCreator.create_normalized_map_grids + create_AF3_encodings_grids  ->  CryoEMPredictor(grids_path).run_prediction()
 
 timed (a) with the in-process hand-off (mica_amd/handoff.py: the volumes stay on the GPU, the tile files are written in the
-background - `write_files=True`, the default - or not at all), (b) with the predictor reading the 25 .npz files per tile (what a
-predictor in another process does), next to (c) the disk-free VolumePredictor on the same map.  All three must agree bit for bit.
+background - `write_files="background"`, what the Solver-flow shim mica_amd/solver_mirrors.py selects -, complete when each wrapper
+returns - "sync", the plain mirrors' default = the reference's contract - or not at all), (b) with the predictor reading the 25 .npz
+files per tile (what a predictor in another process does), next to (c) the disk-free VolumePredictor on the same map.  All must agree
+bit for bit.  Then the WHOLE of getData + nnPred from the raw map and a docked model: plain mirrors (every file complete when its call
+returns) against the shim (every file behind the calls, all present and complete when nnPred returns: the 25 MRC files are hashed and
+a sample of tile files is compared member by member with the synchronous route's).
 usage: python tools/file_predictor_bench.py [n=256]"""
 import os, shutil, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -71,7 +75,8 @@ try:
 
     if n <= 256:
         chain("warm-up (hand-off, no files)", False)
-    T = chain("hand-off, tile files written in the background (default)", True)
+    T = chain("hand-off, tile files written in the background (Solver-flow shim)", "background")
+    chain("hand-off, tile files complete when the wrappers return (plain mirrors' default, 'sync')", "sync")
     chain("hand-off, no tile files (write_files=False)", False)
     chain("predictor reads the tile files (cold path), 4 reader threads", "sync", resident=False)
     # ---- the whole of getData + nnPred (utils/modeler.py:673-738): DataPreprocessor in front, from the raw map and a docked model ----
@@ -94,16 +99,31 @@ try:
     pdb = os.path.join(inp, "9999_af3_docked.pdb")
     open(pdb, "w").write("".join(lines) + "END\n")
 
-    def full_chain(tag, dp_mode, write_files):
+    import hashlib
+    from mica_amd import solver_mirrors
+    from mica_amd import create_grids as plain_cg, preprocessing as plain_pp
+
+    def sha_file(p):
+        h = hashlib.sha256()
+        with open(p, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        return h.hexdigest()
+
+    file_facts = {}
+
+    def full_chain(tag, DP, GC, gc_kw=None, check_files=False):
+        """DP / GC: the DataPreprocessor / GridCreator classes of the route (plain mirrors or the Solver-flow shim), constructed with
+        the arguments the reference's call sites pass (utils/modeler.py:675-706)"""
         shutil.rmtree(grids, ignore_errors=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dp = DataPreprocessor(map_path=raw_path, AF3_results=os.path.join(inp, "AF3_results"), quiet=True, engine=eng, write_files=dp_mode)
+        dp = DP(map_path=raw_path, AF3_results=os.path.join(inp, "AF3_results"), quiet=True, engine=eng)
         dp.resample_and_normalize_map()
         t1 = time.perf_counter()
         assert dp.create_AF3_encodings(pdb) is True
         t2 = time.perf_counter()
-        gc = GridCreator(quiet=True, engine=eng, write_files=write_files)
+        gc = GC(quiet=True, engine=eng, **(gc_kw or {}))
         r1 = gc.create_normalized_map_grids(normalized_map_path=dp.normalized_map_path, output_dir=os.path.join(grids, "normalized_map_grids"))
         r2 = gc.create_AF3_encodings_grids(AF3_encodings_path=os.path.join(inp, "AF3_encodings"), output_dir=os.path.join(grids, "AF3_encoding_grids"))
         assert r1["success"] and r2["success"]
@@ -112,25 +132,42 @@ try:
         ok, vols = pred.run_prediction()
         t4 = time.perf_counter()
         assert ok and pred.resident is not None
+        T = r1["grid_count"]
+        if check_files:
+            # what is on disk when nnPred has returned (outside the clock): every MRC hashed, every tile file counted, a sample compared
+            mrcs = {os.path.basename(dp.normalized_map_path): sha_file(dp.normalized_map_path)}
+            for name in CHANNEL_NAMES:
+                mrcs[name] = sha_file(os.path.join(inp, "AF3_encodings", f"{name}_encoding.mrc"))
+            names = sorted(os.path.relpath(os.path.join(d, f), grids) for d, _, fs in os.walk(grids) for f in fs)
+            assert all(f.endswith(".npz") for f in names), [f for f in names if not f.endswith(".npz")][:3]      # no temporary name left behind
+            sample = names[:: max(1, len(names) // 64)]
+            members = {}
+            for f in sample:
+                z = np.load(os.path.join(grids, f))
+                members[f] = {k: (str(z[k].dtype), z[k].shape, hashlib.sha256(np.ascontiguousarray(z[k]).tobytes()).hexdigest()) for k in z.files}
+            file_facts[tag] = (mrcs, len(names), members)
         shutil.rmtree(grids)
         os.remove(dp.normalized_map_path)
         shutil.rmtree(os.path.join(inp, "AF3_encodings"))                 # what utils/modeler.py:755-757 does
-        T = r1["grid_count"]
         print(f"{tag}: resample+normalise {t1 - t0:.2f} s + AF3 encodings ({nres * 5} atoms) {t2 - t1:.2f} s + tiling {t3 - t2:.2f} s + prediction {t4 - t3:.2f} s "
               f"= {t4 - t0:.2f} s -> {T / (t4 - t0):.1f} sub-grids/s for ALL of getData + nnPred ({T} tiles)", flush=True)
         return vols
 
+    plain, shim = (plain_pp.DataPreprocessor, plain_cg.GridCreator), (solver_mirrors.DataPreprocessor, solver_mirrors.GridCreator)
     if n <= 256:
-        full_chain("getData + nnPred, warm-up", "sync", True)
-    va = full_chain("getData + nnPred, defaults (MRC files complete when each call returns, tile files in the background)", "sync", True)
-    for tag, dp_mode, wf in (("getData + nnPred, every file written behind the calls (DataPreprocessor write_files='background')", "background", True),
-                             ("getData + nnPred, no tile files, MRC files in the background", "background", False)):
-        vb = full_chain(tag, dp_mode, wf)
+        full_chain("getData + nnPred, warm-up", *plain)
+    va = full_chain("getData + nnPred, plain mirrors: every file complete when the call it was asked of returns (the reference's contract)", *plain, check_files=True)
+    for tag, cls, kw, chk in (("getData + nnPred, Solver-flow shim (mica_amd.solver_mirrors): every file written behind the calls, all complete when nnPred returns", shim, None, True),
+                              ("getData + nnPred, shim, no tile files (GridCreator(write_files=False)), MRC files in the background", shim, dict(write_files=False), False)):
+        vb = full_chain(tag, *cls, gc_kw=kw, check_files=chk)
         for k in va:
             assert np.array_equal(va[k], vb[k]), k
         del vb
     del va
-    print("the three full chains agree bit for bit")
+    (m_a, n_a, mem_a), (m_b, n_b, mem_b) = list(file_facts.values())
+    assert m_a == m_b and n_a == n_b == 25 * T and mem_a == mem_b
+    print(f"the three full chains agree bit for bit; plain and shim routes left the same files when nnPred returned: 25 MRC files byte-identical "
+          f"(sha-256), {n_b} tile files each, {len(mem_b)} sampled tile files equal member by member (keys, dtypes, shapes, bytes)")
     vp = VolumePredictor(Engine(0, max_batch=8, tile_size=64), 48, 8, 8)
     vp.e.load_state_dict(w)
     dv, da = torch.from_numpy(np.ascontiguousarray(vol.transpose(2, 1, 0))).cuda(), torch.from_numpy(np.ascontiguousarray(af.transpose(0, 3, 2, 1))).cuda()

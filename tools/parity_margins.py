@@ -56,10 +56,11 @@ for kind in ("heavy", "blob"):
 for case in CASES64:
     g = np.load(os.path.join(G, f"truth64_S64_sub_{case}.npz"))
     st = int(g["stride"])
+    off = [int(q) for q in g["offset"]] if "offset" in g.files else [0, 0, 0]
     w, x, af = case64(case)
     for v in VARIANTS:
-        out = [o[..., ::st, ::st, ::st] for o in run(w, x, af, 64, AF_PER_TILE, v)]
-        line(f"S64 {case} (stride-4 subsample)", v, "reference f32", out, [g[k] for k in ("bb", "ca", "aa")],
+        out = [o[..., off[0]::st, off[1]::st, off[2]::st] for o in run(w, x, af, 64, AF_PER_TILE, v)]
+        line(f"S64 {case} (lattice {st}+{off})", v, "reference f32", out, [g[k] for k in ("bb", "ca", "aa")],
              "reference 1 vs 8 threads rel>1e-4 " + " / ".join(f"{a:.3f}" for a in g["floor_frac_rel"]))
-        line(f"S64 {case} (stride-4 subsample)", v, "float64 truth", out, [g[k] for k in ("bb64", "ca64", "aa64")],
+        line(f"S64 {case} (lattice {st}+{off})", v, "float64 truth", out, [g[k] for k in ("bb64", "ca64", "aa64")],
              "reference f32 vs truth max " + " / ".join(f"{a:.2e}" for a in g["ref32_scaled"]) + " rms " + " / ".join(f"{a:.2e}" for a in g["ref32_rms"]))
