@@ -232,6 +232,20 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
     // instruction; (q, vz, part) are wave-uniform per instruction (w43_dma_*)
     const int dma_vy = (lane >> 3) & 3, dma_quad = lane & 7;
     const int dma_lane = (((lane >> 5) * 4) * Vq + dma_vy * Wq + dma_quad) * 16;
+#ifdef MICA43_WARM
+    // experiment (round 6, review item 4): behind a chunk's last slab DMA every wave TOUCHES the lines of the slab two chunks ahead - one
+    // dword per 128-byte line, result discarded - so that the DMAs of the next chunk find them in the XCD's L2 instead of beyond it.
+    // A wave's warm instruction covers the 8 lines (2 positions x 4 slab rows) of each of ITS six DMAs: lane = (k = lane >> 3, line = lane & 7).
+    int warm_off, warm_yz;
+    {
+        const int k_ = (lane >> 3) < DPW ? (lane >> 3) : 0, l_ = lane & 7;
+        const int ii_ = k_ * DW + wave;
+        const int q_ = ii_ / 18, rem_ = ii_ - q_ * 18, vz_ = rem_ / 3, part_ = rem_ - vz_ * 3;
+        warm_off = ((((part_ * 2) * 4 + q_) * Vq + vz_ * d.H * Wq) + ((l_ >> 2) * 4) * Vq + (l_ & 3) * Wq) * 16;
+        warm_yz = (l_ & 3) | (vz_ << 4);
+    }
+    float warm_sink = 0.f;
+#endif
 #define MICA_SLAB_DMA43(srcbase, bufoff, k, org)                                                                        \
     do {                                                                                                                \
         const int ii_ = (k) * DW + dma_w;                        /* wave-uniform */                                      \
@@ -369,7 +383,11 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                     if (st == 0) { MICA_BLOAD43_SP_LA(wcur); W43_WAITN(4, 2); }                                   // HA: complete since the chunk-end wait
                     else if (st == 1) { MICA_BLOAD43_SP_HB(wcur); }
                     else if (st == 2) { W43_WAITN(4 + W43_NDMA(0) + W43_NDMA(1), 0); }                          // LA; newer: DMA 0, HB, DMA 1
+#ifdef MICA43_WARM
+                    else if (st == 3) { MICA_BLOAD43_SP_LB(wcur); W43_WAITN(4 + W43_NDMA(1) + W43_NDMA(2) + 1, 1); }  // HB; newer: DMA 1, DMA 2, the warm touch, LB
+#else
                     else if (st == 3) { MICA_BLOAD43_SP_LB(wcur); W43_WAITN(4 + W43_NDMA(1) + W43_NDMA(2), 1); }  // HB; newer: DMA 1, DMA 2, LB
+#endif
                     else if (st == 4) { MICA_BLOAD43_SP_HA(wnxt); }                                               // the next chunk's (or item's) HA
                     else if (st == 5) { MICA_BLOAD43_SP_W4(wcur); W43_WAITN(8 + W43_NDMA(3) + W43_NDMA(4), 0); } // LB; newer: DMA 3, HA', DMA 4, W4
                     else { W43_WAITN(W43_NDMA(5), 1); }                                                           // W4; newer: DMA 5
@@ -395,6 +413,20 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                 W43_STAMP(1 + 2 * st);
 #pragma unroll
                 for (int q = 0; q < W43_NDMA(st); ++q) MICA_SLAB_DMA43(nsrc, nxt_off, W43_DMA0(st) + q, org);
+#ifdef MICA43_WARM
+                if constexpr (SPLIT) if (st == 2) {
+                    int g2 = gch + 2;
+                    Item it2 = cur;
+                    if (g2 >= total_chunks) { g2 -= total_chunks; it2 = nxt; }
+                    if (g2 >= total_chunks) g2 = total_chunks - 1;
+                    const char* src2 = reinterpret_cast<const char*>(chunk_base_wino43(s, g2, it2.b, Vq));
+                    int wo = warm_off, wyz = warm_yz;
+                    asm volatile("" : "+v"(wo), "+v"(wyz));
+                    const bool ok2 = (unsigned)(it2.y0 + (wyz & 3)) < (unsigned)d.H && (unsigned)(it2.z0 + (wyz >> 4)) < (unsigned)d.D;
+                    const int go2 = ok2 ? it2.base + wo : 0;
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(warm_sink) : "v"(go2), "s"(src2) : "memory");
+                }
+#endif
                 const char* ab_nxt = ab_cur;
                 if (st + 1 < NS) ab_nxt = W43_ABASE(st + 1);
                 half8 (&b1)[NCT] = bq[SPLIT ? W43_SPSET(st) : (kind == 2 || kind == 4) ? W43_LSET(ps) : W43_HSET(ps)];
@@ -430,6 +462,9 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
             W43_STAMP(30);
             // (SPLIT: the next chunk's HA was requested three steps ago and is OLDER than this chunk's last slab DMA: everything drains)
             if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#ifdef MICA43_WARM
+            asm volatile("" :: "v"(warm_sink));
+#endif
             W43_STAMP(31);
             __syncthreads();
             W43_STAMP(32);
