@@ -280,11 +280,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 #define W16_SET(ls) ((SPLIT && (ls) == 0) ? 2 : ((ls) & 1))
     // slab DMA instructions issued in step ls (9 per wave and chunk, none in the last step so that the chunk-end wait can
     // leave exactly the next chunk's weight loads in flight)
+#if defined(MICA16_DMAPLAN) && MICA16_DMAPLAN == 1        /* experiments (round 6): the nine DMAs of a wave as 0,5,4 ... */
+#define W16_NDMA(ls) (SPLIT ? ((ls) == 1 ? 5 : (ls) == 2 ? 4 : 0) : ((ls) < G::DPW ? 1 : 0))
+#define W16_DMA0(ls) (SPLIT ? ((ls) == 2 ? 5 : 0) : (ls))
+#elif defined(MICA16_DMAPLAN) && MICA16_DMAPLAN == 2      /* 3,3,3 */
+#define W16_NDMA(ls) (SPLIT ? ((ls) < 3 ? 3 : 0) : ((ls) < G::DPW ? 1 : 0))
+#define W16_DMA0(ls) (SPLIT ? 3 * (ls) : (ls))
+#elif defined(MICA16_DMAPLAN) && MICA16_DMAPLAN == 3      /* 0,3,3,3 */
+#define W16_NDMA(ls) (SPLIT ? ((ls) >= 1 && (ls) < 4 ? 3 : 0) : ((ls) < G::DPW ? 1 : 0))
+#define W16_DMA0(ls) (SPLIT ? 3 * ((ls) - 1) : (ls))
+#elif defined(MICA16_DMAPLAN) && MICA16_DMAPLAN == 4      /* 0,9 */
+#define W16_NDMA(ls) (SPLIT ? ((ls) == 1 ? 9 : 0) : ((ls) < G::DPW ? 1 : 0))
+#define W16_DMA0(ls) (SPLIT ? 0 : (ls))
+#else
 #define W16_NDMA(ls) (SPLIT ? ((ls) < 3 ? 2 : (ls) < 6 ? 1 : 0) : ((ls) < G::DPW ? 1 : 0))
+#define W16_DMA0_DEFAULT
+#endif
     // steps in which group 0 holds the high priority: 9 of 14 (0,1,3,4,6,7,9,10,12) resp. 4 of 7 (0,1,3,4); measured flat
     // between 7 and 10 of 14
 #define W16_XHI(ls) (((SPLIT ? 0x1B : 0x16DB) >> (ls)) & 1)
+#ifdef W16_DMA0_DEFAULT
 #define W16_DMA0(ls) (SPLIT ? ((ls) < 3 ? 2 * (ls) : (ls) + 3) : (ls))
+#endif
     // prologue of the first item: slab chunk 0 -> buffer 0, weights of the wave's first step
     int wsel = wn;
     MICA_BLOAD16(W16_SET(0), cur.w, 0);
@@ -358,9 +375,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                 else if (newer == 3) W16_WAIT(3);
                 else if (newer == 4) W16_WAIT(4);
                 else if (newer == 5) W16_WAIT(5);
-                else W16_WAIT(6);
+                else if (newer == 6) W16_WAIT(6);
+                else if (newer == 7) W16_WAIT(7);
+                else if (newer == 8) W16_WAIT(8);
+                else if (newer == 9) W16_WAIT(9);
+                else if (newer == 11) W16_WAIT(11);
+                else W16_WAIT(13);
 #undef W16_WAIT
-                static_assert(W16_NDMA(0) <= 2, "wait immediates above: NCT + 0..2 newer operations");
+                static_assert(NCT + W16_NDMA(0) <= 9 || NCT + W16_NDMA(0) == 11 || NCT + W16_NDMA(0) == 13, "wait immediates above");
+                static_assert(NCT + W16_NDMA(1) <= 9 || NCT + W16_NDMA(1) == 11 || NCT + W16_NDMA(1) == 13, "wait immediates above");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < W16_NDMA(ls); ++q) MICA_SLAB_DMA(nsrc, nxt_off, W16_DMA0(ls) + q, org);

@@ -277,7 +277,13 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
                     for (int k = 0; k < 6; ++k) {
                         const int xx = 4 * i - 1 + k;
                         const bool ok = (unsigned)xx < (unsigned)d.W;
+#ifdef MICA_C1_LINEAR_READS
+                        // timing experiment (results are garbage): neighbouring lanes read NEIGHBOURING rows of the tile (17 slots apart =
+                        // consecutive bank quads: conflict-free under any lane grouping) instead of rows four apart (4-way on ds_read_b128)
+                        const float* tp = T + ((phl + k) & (C1_ROWS - 1)) * C1_TS + kg * 8;
+#else
                         const float* tp = T + (yr * d.W + (ok ? xx : 0)) * C1_TS + kg * 8;
+#endif
                         const float4 a = *reinterpret_cast<const float4*>(tp), c = *reinterpret_cast<const float4*>(tp + 4);
                         dv[k][0] = ok ? a.x : 0.f; dv[k][1] = ok ? a.y : 0.f; dv[k][2] = ok ? a.z : 0.f; dv[k][3] = ok ? a.w : 0.f;
                         dv[k][4] = ok ? c.x : 0.f; dv[k][5] = ok ? c.y : 0.f; dv[k][6] = ok ? c.z : 0.f; dv[k][7] = ok ? c.w : 0.f;
@@ -310,7 +316,11 @@ __global__ __launch_bounds__(C1_NT, NCT == 1 ? 4 : NCT == 2 ? 3 : 2) void conv1x
                     for (int k = 0; k < 4; ++k) {
                         const int xx = 2 * i - 1 + k;
                         const bool ok = (unsigned)xx < (unsigned)d.W;
+#ifdef MICA_C1_LINEAR_READS
+                        const float* tp = T + ((phl + k) & (C1_ROWS - 1)) * C1_TS + kg * 8;      // rows one apart instead of two (2-way)
+#else
                         const float* tp = T + (yr * d.W + (ok ? xx : 0)) * C1_TS + kg * 8;
+#endif
                         const float4 a = *reinterpret_cast<const float4*>(tp), c = *reinterpret_cast<const float4*>(tp + 4);
                         dv[k][0] = ok ? a.x : 0.f; dv[k][1] = ok ? a.y : 0.f; dv[k][2] = ok ? a.z : 0.f; dv[k][3] = ok ? a.w : 0.f;
                         dv[k][4] = ok ? c.x : 0.f; dv[k][5] = ok ? c.y : 0.f; dv[k][6] = ok ? c.z : 0.f; dv[k][7] = ok ? c.w : 0.f;

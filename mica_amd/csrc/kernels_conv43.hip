@@ -190,10 +190,34 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
 #define W43_AOFF_TAP(tap) ((((tap) / 3) * G::PZ + ((tap) % 3) * G::QX) * 16)
 #define W43_PAIRDELTA(ps) ((ps) == 1 ? (G::PZ - 2 * G::QX) * 16 : G::QX * 16)
     // slab DMA slots per wave and step (the first six steps of a chunk), and the first DMA index of a step
-    // (SPLIT: a chunk is seven steps, half as long: the six DMAs go out in its first three steps, two each, so that the last of them
-    // has four steps to land before the chunk-end wait - with one per step it had one, and the wait exposed the HBM latency every chunk)
+    // (SPLIT: a chunk is seven steps, half as long; with one DMA per step the last one had a single step to land before the chunk-end wait)
+#if defined(MICA43_DMAPLAN) && MICA43_DMAPLAN == 0      /* rounds 5's placement: two in each of the first three steps */
 #define W43_NDMA(st) (SPLIT ? ((st) >= 0 && (st) < 3 ? 2 * DPS : 0) : ((st) >= 0 && (st) < 6 ? DPS : 0))
 #define W43_DMA0(st) (SPLIT ? (st) * 2 * DPS : (st) * DPS)
+#elif defined(MICA43_DMAPLAN) && MICA43_DMAPLAN == 2    /* four in step 1, two in step 2 */
+#define W43_NDMA(st) (SPLIT ? ((st) == 1 ? 4 * DPS : (st) == 2 ? 2 * DPS : 0) : ((st) >= 0 && (st) < 6 ? DPS : 0))
+#define W43_DMA0(st) (SPLIT ? ((st) == 2 ? 4 * DPS : 0) : (st) * DPS)
+#elif defined(MICA43_DMAPLAN) && MICA43_DMAPLAN == 3    /* three in step 1, three in step 2 */
+#define W43_NDMA(st) (SPLIT ? ((st) == 1 || (st) == 2 ? 3 * DPS : 0) : ((st) >= 0 && (st) < 6 ? DPS : 0))
+#define W43_DMA0(st) (SPLIT ? ((st) == 2 ? 3 * DPS : 0) : (st) * DPS)
+#elif defined(MICA43_DMAPLAN) && MICA43_DMAPLAN == 4    /* HB requested in step 0 beside LA, all six DMAs behind them: forced complete at step 5, five steps later */
+#define W43_NDMA(st) (SPLIT ? ((st) == 0 ? 6 * DPS : 0) : ((st) >= 0 && (st) < 6 ? DPS : 0))
+#define W43_DMA0(st) (SPLIT ? 0 : (st) * DPS)
+#define MICA43_HB_EARLY
+#elif defined(MICA43_DMAPLAN) && MICA43_DMAPLAN == 5    /* as 4, three DMAs in step 0 and three in step 1 */
+#define W43_NDMA(st) (SPLIT ? ((st) == 0 || (st) == 1 ? 3 * DPS : 0) : ((st) >= 0 && (st) < 6 ? DPS : 0))
+#define W43_DMA0(st) (SPLIT ? ((st) == 1 ? 3 * DPS : 0) : (st) * DPS)
+#define MICA43_HB_EARLY
+#else
+    // SPLIT (round 6): all six right behind HB's request in step 1.  Vector-memory operations retire in order, so a DMA is forced complete
+    // at the first wait for a fragment set requested AFTER it: issued behind HB (step 1) that is the wait for LB in step 5 - four steps
+    // of lead for every DMA, where two per step in steps 0 .. 2 (round 5) gave the first pair three (forced by HB's wait in step 3) and
+    // the last pair three.  2.5-3 % on the 8 .. 16-chunk layers (profiles/r06_warm_l2_ab.txt).  A still longer lead - HB requested in
+    // step 0 beside LA and the DMAs behind both, five steps - is 1 % SLOWER than round 5's: twelve waves then leave the chunk barrier
+    // with eight fragment loads and six DMAs each (variants 4, 5 above).
+#define W43_NDMA(st) (SPLIT ? ((st) == 1 ? 6 * DPS : 0) : ((st) >= 0 && (st) < 6 ? DPS : 0))
+#define W43_DMA0(st) (SPLIT ? 0 : (st) * DPS)
+#endif
     // one fragment set: four 16-cout column tiles, 256 B apart; `delta` (bytes, applied to k-groups 2,3) selects the second tap's units
 #define MICA_BLOAD43(set, base, off, delta)                                                                             \
     do {                                                                                                                \
@@ -380,11 +404,19 @@ __global__ __launch_bounds__(768) void conv_wino43_kernel(ConvSrcs s, const _Flo
                 // next chunk's first H
                 if constexpr (SPLIT) {
                     // in flight and NEWER than the set a step waits for: the fragment sets requested since and the slab DMAs issued since
+#ifdef MICA43_HB_EARLY
+                    if (st == 0) { MICA_BLOAD43_SP_LA(wcur); MICA_BLOAD43_SP_HB(wcur); W43_WAITN(8, 2); }        // HA; newer: LA, HB (set 1: W4 was used up in the previous chunk's last step)
+                    else if (st == 1) { }
+                    else if (st == 2) { W43_WAITN(4 + W43_NDMA(0) + W43_NDMA(1), 0); }                          // LA; newer: HB, DMA 0, DMA 1
+#else
                     if (st == 0) { MICA_BLOAD43_SP_LA(wcur); W43_WAITN(4, 2); }                                   // HA: complete since the chunk-end wait
                     else if (st == 1) { MICA_BLOAD43_SP_HB(wcur); }
                     else if (st == 2) { W43_WAITN(4 + W43_NDMA(0) + W43_NDMA(1), 0); }                          // LA; newer: DMA 0, HB, DMA 1
+#endif
 #ifdef MICA43_WARM
                     else if (st == 3) { MICA_BLOAD43_SP_LB(wcur); W43_WAITN(4 + W43_NDMA(1) + W43_NDMA(2) + 1, 1); }  // HB; newer: DMA 1, DMA 2, the warm touch, LB
+#elif defined(MICA43_HB_EARLY)
+                    else if (st == 3) { MICA_BLOAD43_SP_LB(wcur); W43_WAITN(4 + W43_NDMA(0) + W43_NDMA(1) + W43_NDMA(2), 1); }  // HB; newer: DMA 0, DMA 1, DMA 2, LB
 #else
                     else if (st == 3) { MICA_BLOAD43_SP_LB(wcur); W43_WAITN(4 + W43_NDMA(1) + W43_NDMA(2), 1); }  // HB; newer: DMA 1, DMA 2, LB
 #endif

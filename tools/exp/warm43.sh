@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/warm43
 for rep in 1 2; do
-for v in normal WARM; do
+for v in normal ${WARM43_LIST:-WARM}; do
   if [ $v = normal ]; then L=$PWD/mica_amd/lib/libmica_hip.so; else L=$PWD/tools/exp/libmica43_$v.so; fi
   [ -f $L ] || { echo "missing $L"; exit 1; }
   for cin in 64 128 192 256; do
