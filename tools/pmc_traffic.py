@@ -36,9 +36,24 @@ for name, d in write.items():
     k = short(name)
     if k:
         agg[k]["write"] += sum(d.values()) * 1024
+# conv_wino43_kernel<128> runs encoder.2's four 3^3 convs, always in this order within a forward pass: the per-layer means separate the
+# weight stream (re-read through every XCD's L2 once per round of items) from the operand slabs ("Round 6")
+LAYERS43 = ("encoder.2 conv1 256->128", "encoder.2 conv2 384->128", "encoder.2 conv3 512->256", "encoder.2 transition 256->512")
+per_layer = {}
+for name in fetch:
+    if short(name) == "conv_wino43_kernel<128>":
+        ids = sorted(fetch[name], key=int)
+        wr = write.get(name, {})
+        for pos, lay in enumerate(LAYERS43):
+            sel = ids[pos::4]
+            if sel and len(ids) % 4 == 0:
+                per_layer[lay] = {"launches": len(sel), "hbm_read_bytes": sum(fetch[name][i] for i in sel) * 2048 / len(sel),
+                                  "hbm_write_bytes": sum(wr.get(i, 0.0) for i in sel) * 1024 / len(sel)}
 for k, v in agg.items():
     n = max(v["launches"], 1)
     out["kernels"][k] = {"launches": v["launches"], "hbm_read_bytes": v["fetch"] / n, "hbm_write_bytes": v["write"] / n,
                          "hbm_bytes": (v["fetch"] + v["write"]) / n}
+if per_layer:
+    out["kernels"]["conv_wino43_kernel<128>"]["per_layer"] = per_layer
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
