@@ -191,7 +191,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
     const int64_t nbstride = (int64_t)total_chunks * chstride;
     const char* wwave = reinterpret_cast<const char*>(wpk) + wp * 8 * ustride + (SPLIT ? 0 : wn * WNC * 16);
 
-    half8 bq[3][NCT];        // weight fragment sets; the third only when NS is odd (see W16_SET)
+#ifdef MICA16_TWOAHEAD
+    // experiment (round 6): in the tap-split variants the fragments of step ls + 2 are requested in step ls (four register sets, set =
+    // ls & 3: the assignment closes over the seven steps of a chunk), so that a slab DMA issued in step ls is forced complete by the
+    // in-order queue at the wait of step ls + 3 instead of ls + 2
+    constexpr bool TWOAHEAD = SPLIT;
+#else
+    constexpr bool TWOAHEAD = false;
+#endif
+    half8 bq[TWOAHEAD ? 4 : 3][NCT];        // weight fragment sets; the third only when NS is odd (see W16_SET)
     // step parameters: global step st (0..13) -> scalars; a wave's local step ls is global step ls (+ 7 for group 1 of BN = 64)
 #define W16_TAP(st) (2 * w16_step_ps(st) + (w16_step_kind(st) == 1 ? 1 : 0))
 #define W16_AOFF(st) (((W16_TAP(st) / 3) * G::PZ + (W16_TAP(st) % 3) * 8) * 16)
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 
     // step ls of a wave's NS uses set W16_SET(ls): alternating, except that with NS odd the first step of a chunk has a set
     // of its own (its fragments are fetched during the last step of the previous chunk, which uses set 0 itself)
-#define W16_SET(ls) ((SPLIT && (ls) == 0) ? 2 : ((ls) & 1))
+#define W16_SET(ls) (TWOAHEAD ? ((ls) & 3) : (SPLIT && (ls) == 0) ? 2 : ((ls) & 1))
     // slab DMA instructions issued in step ls (9 per wave and chunk, none in the last step so that the chunk-end wait can
     // leave exactly the next chunk's weight loads in flight)
 #if defined(MICA16_DMAPLAN) && MICA16_DMAPLAN == 1        /* experiments (round 6): the nine DMAs of a wave as 0,5,4 ... */
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
     // prologue of the first item: slab chunk 0 -> buffer 0, weights of the wave's first step
     int wsel = wn;
     MICA_BLOAD16(W16_SET(0), cur.w, 0);
+    if constexpr (TWOAHEAD) MICA_BLOAD16(W16_SET(1), cur.w, 1);
 #pragma unroll
     for (int k = 0; k < G::DPW; ++k) MICA_SLAB_DMA(cur.src0, 0, k, cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -365,10 +374,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 #pragma unroll
             for (int ls = 0; ls < NS; ++ls) {
                 half8 (&bc)[NCT] = bq[W16_SET(ls)];
-                if (ls + 1 < NS) MICA_BLOAD16(W16_SET(ls + 1), wcur, ls + 1);
-                else MICA_BLOAD16(W16_SET(0), wnxt, 0);
+                if constexpr (TWOAHEAD) {
+                    if (ls + 2 < NS) MICA_BLOAD16(W16_SET(ls + 2), wcur, ls + 2);
+                    else MICA_BLOAD16(W16_SET(ls + 2 - NS), wnxt, ls + 2 - NS);
+                } else {
+                    if (ls + 1 < NS) MICA_BLOAD16(W16_SET(ls + 1), wcur, ls + 1);
+                    else MICA_BLOAD16(W16_SET(0), wnxt, 0);
+                }
                 // in flight and NEWER than this step's fragments: the NCT loads just issued plus the previous step's slab DMAs
-                const int newer = NCT + (ls >= 1 ? W16_NDMA(ls - 1) : 0);
+                // (TWOAHEAD: the loads of the previous and of this step, and the DMAs of the two steps before this one - at the head of a
+                // chunk those of the previous chunk's last steps)
+                const int newer = TWOAHEAD ? 2 * NCT + W16_NDMA((ls + NS - 1) % NS) + W16_NDMA((ls + NS - 2) % NS)
+                                           : NCT + (ls >= 1 ? W16_NDMA(ls - 1) : 0);
 #define W16_WAIT(N) do { if (NCT == 4) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bc[0]), "+v"(bc[1]), "+v"(bc[NCT - 2]), "+v"(bc[NCT - 1])); \
                          else asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bc[0]), "+v"(bc[1])); } while (0)
                 if (newer == 2) W16_WAIT(2);
@@ -379,7 +396,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
                 else if (newer == 7) W16_WAIT(7);
                 else if (newer == 8) W16_WAIT(8);
                 else if (newer == 9) W16_WAIT(9);
+                else if (newer == 10) W16_WAIT(10);
                 else if (newer == 11) W16_WAIT(11);
+                else if (newer == 12) W16_WAIT(12);
                 else W16_WAIT(13);
 #undef W16_WAIT
                 static_assert(NCT + W16_NDMA(0) <= 9 || NCT + W16_NDMA(0) == 11 || NCT + W16_NDMA(0) == 13, "wait immediates above");
@@ -428,6 +447,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
         // move their registers freely through the epilogue and the loop back edge (it cannot see that they were in flight)
         if (NCT == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[W16_SET(0)][0]), "+v"(bq[W16_SET(0)][1]), "+v"(bq[W16_SET(0)][NCT - 2]), "+v"(bq[W16_SET(0)][NCT - 1]));
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[W16_SET(0)][0]), "+v"(bq[W16_SET(0)][1]));
+        if constexpr (TWOAHEAD) {       // ... and those of its second step
+            if (NCT == 4) asm volatile("" : "+v"(bq[W16_SET(1)][0]), "+v"(bq[W16_SET(1)][1]), "+v"(bq[W16_SET(1)][NCT - 2]), "+v"(bq[W16_SET(1)][NCT - 1]));
+            else asm volatile("" : "+v"(bq[W16_SET(1)][0]), "+v"(bq[W16_SET(1)][1]));
+        }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU/LDS readers: the hazard the compiler cannot see through the asm
 
         // ---- output transform through the idle slab buffer (the other one already holds the next item's first chunk) ----
@@ -575,6 +598,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino16_kernel(ConvSrcs s, const _
 #undef MICA_SLAB_DMA
     // nothing may still be in flight towards this workgroup's registers or LDS when it ends
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[W16_SET(0)][0]), "+v"(bq[W16_SET(0)][1]), "+v"(bq[W16_SET(0)][NCT - 2]), "+v"(bq[W16_SET(0)][NCT - 1]));
+    if constexpr (TWOAHEAD) asm volatile("" : "+v"(bq[W16_SET(1)][0]), "+v"(bq[W16_SET(1)][1]), "+v"(bq[W16_SET(1)][NCT - 2]), "+v"(bq[W16_SET(1)][NCT - 1]));
 #undef W16_SET
 #undef W16_NDMA
 #undef W16_DMA0

@@ -55,6 +55,26 @@ def test_batchwide_gating_quirk(weights, golden_dir):
     assert float((pb[1] - bb[1]).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("tag,wseed,gain", [("w2022g6", 2022, 6.0), ("w7g3", 7, 3.0), ("w99g10", 99, 10.0)])
+def test_oracle_float64_mode_is_the_references_double_run(golden_dir, tag, wseed, gain):
+    """`mica_forward(dtype=torch.float64)` - the oracle's "exact answer" mode, what tools/parity_full_tile.py and the whole-tile GPU test
+    compare with on the GPU box - against the reference module run as `MICA().double()` (oracle/noise_floor.py --truth, committed as
+    tests/golden/truth64_S16_<weights>.npz): bit for bit.  (At 64^3 oracle/gen_golden_r5.py asserts the same on every logit of the
+    sixteen tiles: manifest.json["oracle64_vs_reference64_maxabs"].)"""
+    import json
+    from mica_amd.synth import synth_af, synth_density
+    from mica_amd.weights import synth_state_dict
+    g = np.load(os.path.join(golden_dir, f"truth64_S16_{tag}.npz"))
+    x = synth_density((1, 1, 16, 16, 16), int(g["seed"]))
+    af = synth_af((16, 16, 16), int(g["seed"]), float(g["afp"]))[None]
+    out = mo.mica_forward(synth_state_dict(wseed, gain), x, af, dtype=torch.float64)
+    for o, k in zip(out, ("bb", "ca", "aa")):
+        assert o.dtype == torch.float64 and np.array_equal(o.numpy(), g[k]), k
+    m = json.load(open(os.path.join(golden_dir, "manifest.json")))
+    assert len(m["oracle64_vs_reference64_maxabs"]) == 16 and max(m["oracle64_vs_reference64_maxabs"].values()) == 0.0
+    assert max(m["oracle32_vs_reference32_maxabs_S64"].values()) == 0.0 and m["S64_lattice"] == {"stride": 5, "offset": [1, 2, 3]}
+
+
 def test_postprocess_properties():
     g = torch.Generator().manual_seed(3)
     bb, ca, aa = (torch.randn((2, c, 4, 4, 4), generator=g) * 3 for c in (4, 4, 21))

@@ -501,3 +501,12 @@ def test_command_line_entry_map_to_volumes(tmp_path, eng, weights):
     for k, v in ref.items():
         got = np.load(os.path.join(out, f"{k}.npy"))
         assert got.dtype == np.float32 and np.array_equal(got, v.cpu().numpy()), k
+    # the same command on two ranks (`--gpus 2`: this box has one GPU, so both ranks on cuda:0 over gloo): the CLI process is rank 0 and
+    # starts the worker itself (mica_amd/multi.py); same files, bit for bit
+    out2 = str(tmp_path / "out2")
+    r = subprocess.run([sys.executable, "-m", "mica_amd", "--map", mp, "--model", ck, "--docked-model", str(pdb), "--out", out2, "--batch", "4",
+                        "--gpus", "2", "--rank-backend", "gloo", "--rank-devices", "0,0"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ranks 2 backend gloo" in r.stdout and "rank 1: python + torch import" in r.stdout
+    for k in ref:
+        assert np.array_equal(np.load(os.path.join(out2, f"{k}.npy")), np.load(os.path.join(out, f"{k}.npy"))), k

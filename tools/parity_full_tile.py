@@ -89,8 +89,10 @@ def main():
             g = gpu_logits(w, x, af, v)
             for what, ref in (("oracle f32", o32), ("oracle f64", o64)):
                 ms = [metrics(gg, rr) for gg, rr in zip(g, ref)]
+                spread = max(abs(p / m["rms"] - 1.0) for m in ms for ax in m["pos"].values() for p in ax)
                 print(f"{case:18s} v{v} vs {what}: " + "  ".join(
-                    f"{h} max {m['max']:.2e} rms {m['rms']:.2e} rel>1e-4 {m['frac']:.3f} at {m['argmax']}->{m['res']}" for h, m in zip(HEADS, ms)), flush=True)
+                    f"{h} max {m['max']:.2e} rms {m['rms']:.2e} rel>1e-4 {m['frac']:.3f} at {m['argmax']}->{m['res']}" for h, m in zip(HEADS, ms))
+                      + f"  | rms per tile position (x%4, y%2, z%4) within {100 * spread:.1f} % of the tile's", flush=True)
                 for h, m in zip(HEADS, ms):
                     k = (v, what)
                     worst[k] = max(worst.get(k, (0, None, None)), (m["max"], case, h))

@@ -7,7 +7,8 @@
 #   profile    rocprofv3 passes of bench.py (tools/profile.sh)    -> kernel_stats.txt/.csv, pmc_sq_summary.txt, pmc_traffic.json (stamped
 #                                                                    with the library source hash bench.py checks)
 #   bench      the default bench line                             -> bench_default.json
-#   parity     tools/parity_full_tile.py (every logit of the sixteen 64^3 tiles vs the oracle, f32 and f64) -> parity_full_tile.txt
+#   parityA, parityB   tools/parity_full_tile.py (every logit of the sixteen 64^3 tiles vs the oracle, f32 and f64; ~75 s of CPU per tile: two
+#              calls of eight tiles)                               -> parity_full_tile_a.txt, _b.txt (copy joins them: parity_full_tile.txt)
 #   margins    tools/parity_margins.py 0,1,3 (every fixture, lattice samples)                                -> parity_margins.txt
 #   files      getData + nnPred through the mirrors, 256^3        -> file_predictor.txt          files512: the same at 512^3
 #   ranks      rank start-up of the multi-GPU product entry       -> rank_startup.txt
@@ -24,7 +25,8 @@ if [ "$1" = copy ]; then
   cpy() { [ -f "$T/$1" ] && grep -v amdgpu.ids "$T/$1" > "profiles/${R}_$2" && echo "profiles/${R}_$2"; }
   cpy bench_default.json bench_default.json; cpy kernel_stats.txt kernel_stats.txt; [ -f $T/stats/r_kernel_stats.csv ] && cp $T/stats/r_kernel_stats.csv profiles/${R}_kernel_stats.csv
   cpy pmc_sq_summary.txt pmc_sq_summary.txt; [ -f $T/pmc_traffic.json ] && cp $T/pmc_traffic.json profiles/${R}_pmc_traffic.json
-  for f in parity_full_tile.txt parity_margins.txt file_predictor.txt file_predictor_512.txt rank_startup.txt e2e_streamed.txt soak.txt mixed_af_ab.txt; do cpy $f $f; done
+  [ -f $T/parity_full_tile_a.txt ] && [ -f $T/parity_full_tile_b.txt ] && cat $T/parity_full_tile_a.txt $T/parity_full_tile_b.txt | grep -v amdgpu.ids > profiles/${R}_parity_full_tile.txt && echo profiles/${R}_parity_full_tile.txt
+  for f in parity_margins.txt file_predictor.txt file_predictor_512.txt rank_startup.txt e2e_streamed.txt soak.txt mixed_af_ab.txt; do cpy $f $f; done
   for f in $T/bench_strong_*.json $T/bench_2rank_*.json; do [ -f "$f" ] && cp $f profiles/${R}_$(basename $f) && echo profiles/${R}_$(basename $f); done
   tail -1 $T/t_all.log 2>/dev/null; cat $T/source_hash.txt 2>/dev/null
   exit 0
@@ -40,7 +42,8 @@ for step in "$@"; do
     tests)    timeout -k 10 1000 python -m pytest tests -x -q -m gpu -s > $T/t_all.log 2>&1; r=$?; echo "gpu tests rc=$r"; tail -3 $T/t_all.log; [ $r -eq 0 ] || exit $r ;;
     profile)  bash tools/profile.sh $R stats sq fetch write > $T/profile.log 2>&1; echo "profile rc=$?"; head -14 $T/pmc_sq_summary.txt ;;
     bench)    run bench bench_default.json 400 python bench.py && head -c 400 $T/bench_default.json && echo ;;
-    parity)   run parity parity_full_tile.txt 1100 python tools/parity_full_tile.py && tail -30 $T/parity_full_tile.txt ;;
+    parity|parityA)  run parityA parity_full_tile_a.txt 1100 python tools/parity_full_tile.py --cases w2022g6,w7g3,w99g10,zeroaf_w2022g6,blob,heavy,w99g10_s101,w99g10_s102 && tail -12 $T/parity_full_tile_a.txt ;;
+    parityB)  run parityB parity_full_tile_b.txt 1100 python tools/parity_full_tile.py --cases w99g10_s103,w99g10_s104,w7g3_s201,w7g3_s202,w2022g6_s201,w2022g6_s202,w31g6_s301,w57g10_s302 && tail -12 $T/parity_full_tile_b.txt ;;
     margins)  run margins parity_margins.txt 900 python tools/parity_margins.py 0,1,3 && tail -4 $T/parity_margins.txt ;;
     files)    run files file_predictor.txt 400 python tools/file_predictor_bench.py 256 && cat $T/file_predictor.txt ;;
     files512) run files512 file_predictor_512.txt 900 python tools/file_predictor_bench.py 512 && cat $T/file_predictor_512.txt ;;
