@@ -142,6 +142,8 @@ def serve(rank: int, world: int, port: int, backend: str, device_index: int, run
     marks = {"spawned": t_spawn, "imported": time.time()}
     runner = _resolve(runner_spec)(device_index, tile, batch, conv_variant)
     marks["engine"] = time.time()
+    if getattr(getattr(runner, "device", None), "type", "cpu") == "cuda":
+        torch.cuda.set_device(runner.device)        # this rank's GPU is the current device for everything the group creates
     # "ready" before the group: rank 0 enters the (uninterruptible) rendezvous only when every worker stands here, so a worker that
     # died on its way up is seen by a poll of its process, not by a collective's time-out
     store = _store(port, world, False, timeout_s)
