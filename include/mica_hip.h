@@ -51,7 +51,7 @@ typedef struct mica_ctx mica_ctx;
 #define MICA_AF_ALWAYS 3    /* no test: every tile takes the AF3 branch - for a caller that cut one batch into several calls and
                                evaluated the batch-wide test itself (mica_amd/engine.py does for batches beyond max_batch)      */
 
-int mica_abi_version(void);
+int mica_abi_version(void);   /* 3 (round 6: mica_get_last_forward_input_runs, mica_get_last_forward_af_tiles); bumped with every export or struct change */
 
 /* ---- context ---------------------------------------------------------------------------- */
 /* Allocates the activation workspace for up to max_batch tiles of tile_size^3 voxels in flight (about 4.6 GB per 64^3 tile).

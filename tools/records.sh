@@ -16,6 +16,8 @@
 #   rehearse   bench.py --gpus 2 --backend gloo --single-device (weak, root, strong): two ranks SHARING one GPU - functional, not scaling
 #   e2e        tools/e2e_bench.py 384 4 (configs[4], host -> host) -> e2e_streamed.txt
 #   soak       tools/soak.py 1500 8                               -> soak.txt
+#   fuzz       tools/fuzz_ops.py (random shapes through the single-op entries, 300 s + 200 s big) -> fuzz_ops.txt
+#   fuzzvol    tests/test_gpu_fuzz_volume.py for 90 s per family  -> fuzz_volume.txt
 #   mixed      the A/B of the one-pass forward on a map with atoms in 30 % of the box (MICA_TRUNK_PER_RUN=1 | 0) -> mixed_af_ab.txt
 set -o pipefail
 R=${1:?usage: tools/records.sh <rNN> step...}; shift
@@ -26,7 +28,7 @@ if [ "$1" = copy ]; then
   cpy bench_default.json bench_default.json; cpy kernel_stats.txt kernel_stats.txt; [ -f $T/stats/r_kernel_stats.csv ] && cp $T/stats/r_kernel_stats.csv profiles/${R}_kernel_stats.csv
   cpy pmc_sq_summary.txt pmc_sq_summary.txt; [ -f $T/pmc_traffic.json ] && cp $T/pmc_traffic.json profiles/${R}_pmc_traffic.json
   [ -f $T/parity_full_tile_a.txt ] && [ -f $T/parity_full_tile_b.txt ] && cat $T/parity_full_tile_a.txt $T/parity_full_tile_b.txt | grep -v amdgpu.ids > profiles/${R}_parity_full_tile.txt && echo profiles/${R}_parity_full_tile.txt
-  for f in parity_margins.txt file_predictor.txt file_predictor_512.txt rank_startup.txt e2e_streamed.txt soak.txt mixed_af_ab.txt; do cpy $f $f; done
+  for f in fuzz_ops.txt fuzz_volume.txt parity_margins.txt file_predictor.txt file_predictor_512.txt rank_startup.txt e2e_streamed.txt soak.txt mixed_af_ab.txt; do cpy $f $f; done
   for f in $T/bench_strong_*.json $T/bench_2rank_*.json; do [ -f "$f" ] && cp $f profiles/${R}_$(basename $f) && echo profiles/${R}_$(basename $f); done
   tail -1 $T/t_all.log 2>/dev/null; cat $T/source_hash.txt 2>/dev/null
   exit 0
@@ -40,7 +42,9 @@ run() { local name=$1 out=$2 lim=$3; shift 3; timeout -k 10 $lim "$@" > $T/$out 
 for step in "$@"; do
   case $step in
     tests)    timeout -k 10 1000 python -m pytest tests -x -q -m gpu -s > $T/t_all.log 2>&1; r=$?; echo "gpu tests rc=$r"; tail -3 $T/t_all.log; [ $r -eq 0 ] || exit $r ;;
-    profile)  bash tools/profile.sh $R stats sq fetch write > $T/profile.log 2>&1; echo "profile rc=$?"; head -14 $T/pmc_sq_summary.txt ;;
+    profile)  bash tools/profile.sh $R stats sq fetch write > $T/profile.log 2>&1; echo "profile rc=$?"; head -14 $T/pmc_sq_summary.txt
+              # a `bench` step later in this call quotes the counters of THIS tree (bench.py reads the newest profiles/rNN_pmc_*)
+              cp $T/pmc_traffic.json profiles/${R}_pmc_traffic.json 2>/dev/null; cp $T/pmc_sq_summary.txt profiles/${R}_pmc_sq_summary.txt 2>/dev/null ;;
     bench)    run bench bench_default.json 400 python bench.py && head -c 400 $T/bench_default.json && echo ;;
     parity|parityA)  run parityA parity_full_tile_a.txt 1100 python tools/parity_full_tile.py --cases w2022g6,w7g3,w99g10,zeroaf_w2022g6,blob,heavy,w99g10_s101,w99g10_s102 && tail -12 $T/parity_full_tile_a.txt ;;
     parityB)  run parityB parity_full_tile_b.txt 1100 python tools/parity_full_tile.py --cases w99g10_s103,w99g10_s104,w7g3_s201,w7g3_s202,w2022g6_s201,w2022g6_s202,w31g6_s301,w57g10_s302 && tail -12 $T/parity_full_tile_b.txt ;;
@@ -57,6 +61,10 @@ for step in "$@"; do
               run strong2 bench_strong_2rank_gloo_one_gpu_256.json 400 python bench.py --gpus 2 --backend gloo --single-device --strong --map 256 --grid 48 --pad 8 ;;
     e2e)      run e2e e2e_streamed.txt 300 python tools/e2e_bench.py 384 4 && tail -3 $T/e2e_streamed.txt ;;
     soak)     run soak soak.txt 600 python tools/soak.py 1500 8 && tail -2 $T/soak.txt ;;
+    fuzz)     timeout -k 10 420 python tools/fuzz_ops.py 300 6 > $T/fuzz_a.log 2> $T/fuzz.err; echo "fuzz rc=$?"
+              timeout -k 10 300 python tools/fuzz_ops.py 200 7 big > $T/fuzz_b.log 2>> $T/fuzz.err; echo "fuzz big rc=$?"
+              { echo "# tools/fuzz_ops.py 300 6:"; tail -12 $T/fuzz_a.log; echo "# tools/fuzz_ops.py 200 7 big:"; tail -12 $T/fuzz_b.log; } > $T/fuzz_ops.txt; tail -3 $T/fuzz_a.log; tail -3 $T/fuzz_b.log ;;
+    fuzzvol)  MICA_FUZZ_SECONDS=90 timeout -k 10 600 python -m pytest tests/test_gpu_fuzz_volume.py -q -m gpu -s > $T/fuzz_volume.txt 2>&1; echo "fuzz volume rc=$?"; tail -3 $T/fuzz_volume.txt ;;
     mixed)    : > $T/mixed_af_ab.txt
               for v in 1 0 1 0; do
                 MICA_TRUNK_PER_RUN=$v timeout -k 10 300 python bench.py --no-cpu-baseline --no-alt-tiling --no-whole-map > $T/mixed_$v.json 2> $T/mixed.err || { rc=1; tail -3 $T/mixed.err; }
