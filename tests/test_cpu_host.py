@@ -590,9 +590,29 @@ def test_file_modes_of_the_mirrors_and_of_the_solver_shim(monkeypatch):
     assert solver_mirrors.CryoEMPredictor is CryoEMPredictor
 
 
-def _fake_pool(**kw):
+def _fake_pool(world=2, **kw):
     from mica_amd.multi import RankPool
-    return RankPool(2, tile=16, batch=2, backend="gloo", devices=[0, 0], runner="tests.multi_fake:FakeRunner", timeout_s=60, **kw)
+    return RankPool(world, tile=16, batch=2, backend="gloo", devices=[0] * world, runner="tests.multi_fake:FakeRunner", timeout_s=60, **kw)
+
+
+def test_rank_pool_eight_ranks_as_on_a_node(tmp_path):
+    """The pool at the node's size: rank 0 + seven workers over gloo with the stand-in runner; 30 batches over 8 ranks = 4 rounds, the last
+    with idle ranks; every worker reports its start-up once and leaves with exit code 0."""
+    from tests.multi_fake import FakeRunner
+    ck = tmp_path / "ckpt.txt"
+    ck.write_text("0.5")
+    pool = _fake_pool(8).spawn()
+    try:
+        procs = list(pool.procs)
+        assert len(procs) == 7
+        vol = torch.arange(40 * 24 * 17, dtype=torch.float32).reshape(40, 24, 17)            # 5 x 3 x 3 = 45 tiles of 8^3 -> 23 batches of 2
+        out = pool.predict(FakeRunner(0, 16, 2), str(ck), vol, None, grid=8, pad=0)
+        assert np.array_equal(out["volume"], (vol * 0.5).numpy())
+        assert sorted(s["rank"] for s in pool.startup) == list(range(1, 8)) and [s["rank"] for s in pool.last_status] == list(range(8))
+        assert pool.last_status[0]["stats"]["world"] == 8 and pool.last_status[0]["stats"]["collectives"] == 3      # ceil(23 / 8) rounds
+    finally:
+        pool.close()
+    assert [p.returncode for p in procs] == [0] * 7 and not torch.distributed.is_initialized()
 
 
 def test_rank_pool_two_ranks_persistent_workers_and_clean_shutdown(tmp_path):
