@@ -276,8 +276,12 @@ class CryoEMPredictor:
                 self.rank_pool = pool = multi.get_pool(self.gpus, tile=self.engine.tile_size, batch=self.engine.max_batch, backend=self.rank_backend,
                                                        devices=self.rank_devices, conv_variant=None)
                 runner = multi.EngineRunner(None, self.engine.tile_size, self.engine.max_batch, engine=self.engine, loaded_model=self.model_path)
-                vols = pool.predict(runner, self.model_path, m.volume, af, m.grid_size, m.padding, gather_to_root=self.gather_to_root, to_host=True)
-                self.engine = runner.engine
+                try:
+                    vols = pool.predict(runner, self.model_path, m.volume, af, m.grid_size, m.padding, gather_to_root=self.gather_to_root, to_host=True)
+                finally:
+                    if runner.engine is not self.engine:      # the runner had to build a fresh context (the checkpoint changed under it)
+                        self.engine.close()
+                        self.engine = runner.engine
             else:
                 vols = VolumePredictor(self.engine, m.grid_size, m.padding, self.engine.max_batch).predict_volume(m.volume, af, to_host=True)
             self.timing_stats['inference'] = time.time() - t0
