@@ -419,9 +419,12 @@ class RankPool:
 
 
 def get_pool(gpus: int, tile: int = 64, batch: int = 8, backend: str | None = None, devices=None, conv_variant=None,
-             runner: str = DEFAULT_RUNNER) -> RankPool:
-    """The process-wide pool for this configuration (workers persist from map to map; another configuration replaces it)."""
+             runner: str | None = None) -> RankPool:
+    """The process-wide pool for this configuration (workers persist from map to map; another configuration replaces it).
+    runner: "module:factory" of the per-rank compute object (default: the HIP path, `EngineRunner`; MICA_RANK_RUNNER overrides it -
+    the CPU tests put a stand-in there)."""
     backend = backend or os.environ.get("MICA_RANK_BACKEND", "nccl")
+    runner = runner or os.environ.get("MICA_RANK_RUNNER", DEFAULT_RUNNER)
     key = (int(gpus), int(tile), int(batch), backend, None if devices is None else tuple(devices), conv_variant, runner)
     with _LOCK:
         p = _POOLS.get(key)

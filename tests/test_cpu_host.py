@@ -686,6 +686,28 @@ def test_rank_pool_worker_failures_end_loudly_and_leave_no_process(tmp_path, mon
     assert not torch.distributed.is_initialized()
 
 
+def test_solver_shim_starts_the_worker_ranks_when_getdata_begins(monkeypatch, tmp_path):
+    """With MICA_GPUS > 1 the Solver-flow shim starts the worker ranks when `DataPreprocessor` is constructed - the first line of
+    getData (reference utils/modeler.py:675) - so that their python + torch import and their engines come up beside the normaliser and
+    the tilers; the predictor later asks for the pool of the same configuration and finds THOSE processes.  (Stand-in runner: no GPU.)"""
+    from mica_amd import multi, solver_mirrors
+    multi.shutdown()
+    monkeypatch.setenv("MICA_GPUS", "2")
+    monkeypatch.setenv("MICA_RANK_BACKEND", "gloo")
+    monkeypatch.setenv("MICA_RANK_RUNNER", "tests.multi_fake:FakeRunner")
+    try:
+        solver_mirrors.DataPreprocessor(str(tmp_path / "emd.mrc"), str(tmp_path / "AF3_results"), quiet=True)
+        pool = multi.get_pool(2, tile=64, batch=8)                   # what CryoEMPredictor.run_prediction asks for with the defaults
+        assert len(pool.procs) == 1 and pool.procs[0].poll() is None and not pool.joined and pool.t_spawn is not None
+        worker = pool.procs[0]
+        assert multi.get_pool(2, tile=64, batch=8) is pool
+        other = multi.get_pool(2, tile=64, batch=4)                  # another configuration replaces the pool: the old worker is gone first
+        assert other is not pool and pool.closed and worker.poll() is not None
+    finally:
+        multi.shutdown()
+    assert multi._POOLS == {}
+
+
 def test_engine_methods_run_under_the_engines_lock():
     """A context is not thread-safe (include/mica_hip.h) and the tile-file writer shares the tiler's engine from its own thread:
     every public Engine method takes the engine's re-entrant lock (mica_amd/engine.py)."""

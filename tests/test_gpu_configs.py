@@ -190,7 +190,7 @@ def test_training_tilers_create_and_save_grids(tmp_path, eng):
     assert gc.create_and_save_grids(str(tmp_path / "missing.mrc"), str(tmp_path / "x")) == 0
 
 
-def test_config2_through_the_product_entry_two_ranks_on_one_gpu(tmp_path, weights):
+def test_config2_through_the_product_entry_two_ranks_on_one_gpu(tmp_path, weights, monkeypatch):
     """BASELINE configs[2] behind the boundary the reference calls: ONE process builds `CryoEMPredictor(...)` and calls
     `run_prediction()` (utils/modeler.py:722-738).  `gpus=2`: this process is rank 0, rank 1 is a fresh child that
     mica_amd/multi.py starts; the volumes GridCreator left on the GPU are broadcast to it, both run their share of the tile batches,
@@ -280,6 +280,40 @@ def test_config2_through_the_product_entry_two_ranks_on_one_gpu(tmp_path, weight
     finally:
         pool.close()
     assert not torch.distributed.is_initialized()
+    handoff.clear()
+    # the whole Solver flow through the import shim with MICA_GPUS=2 in the environment: the worker is started
+    # when DataPreprocessor is constructed - beside getData -, the predictor finds that very process, the volumes equal one GPU's
+    from mica_amd import solver_mirrors as sm
+    multi.shutdown()
+    raw = ((synth_density((50, 40, 100), 93) - 0.3) * 3.0).astype(np.float32)
+    inp = tmp_path / "solver" / "9999"
+    os.makedirs(inp / "AF3_results")
+    mrc.write_mrc(str(inp / "emd_9999.mrc"), raw)
+
+    def solver_flow(tag):
+        import time
+        t0 = time.time()
+        dp = sm.DataPreprocessor(map_path=str(inp / "emd_9999.mrc"), AF3_results=str(inp / "AF3_results"), quiet=True)
+        dp.resample_and_normalize_map()
+        grids = str(tmp_path / "solver" / tag)
+        gc = sm.GridCreator(quiet=True)
+        assert gc.create_normalized_map_grids(normalized_map_path=dp.normalized_map_path, output_dir=os.path.join(grids, "normalized_map_grids"))["success"]
+        pred = sm.CryoEMPredictor(model_path=ck, grids_path=grids + "/", output_path=str(tmp_path / "out"), save_output=False, device="cuda", quiet=True)
+        ok, vols = pred.run_prediction()
+        assert ok and len(glob.glob(os.path.join(grids, "normalized_map_grids", "*.npz"))) == 6       # the shim's background files, complete on return
+        return vols, pred, t0
+    one, _, _ = solver_flow("one")
+    monkeypatch.setenv("MICA_GPUS", "2")
+    monkeypatch.setenv("MICA_RANK_BACKEND", "gloo")
+    monkeypatch.setenv("MICA_RANK_DEVICES", "0,0")
+    try:
+        two, pred, t0 = solver_flow("two")
+        assert pred.gpus == 2 and pred.rank_pool is not None and pred.rank_pool.maps == 1 and pred.rank_pool.last_status[0]["stats"]["world"] == 2
+        assert pred.rank_pool.t_spawn - t0 < 0.5                       # spawned by DataPreprocessor's constructor, not by the predictor
+        for k in one:
+            assert np.array_equal(one[k], two[k]), k
+    finally:
+        multi.shutdown()
     handoff.clear()
 
 
