@@ -485,6 +485,13 @@ def main():
         roof["all_dense_convs"] = {"algorithmic_tflops": ach_all, "launches_per_batch": launches, "ms_per_batch": ms,
                                    "note": "3x3x3 and 1x1x1 launches together (the 1x1 kernel is HBM-bound and also does the operand passes)"}
         roof["profile_source"] = {"library_source_hash": here, "traffic": tnote, "counters": sqnote}
+        per_layer = traffic.get("conv_wino43_kernel<128>", {}).get("per_layer")
+        if per_layer:
+            roof["traffic_by_layer_read_bytes"] = {k: v["hbm_read_bytes"] for k, v in per_layer.items()}
+            roof["traffic_note"] = ("FETCH_SIZE / WRITE_SIZE count requests at the L2's fabric side, Infinity-Cache hits included; by layer the reads are "
+                                    "'packed weights once per XCD round of items + 1.2 x the operand' to 1 % - two thirds are re-reads of <= 31.5 MB of "
+                                    "weights, a table that stays in the 256-MB Infinity Cache (DESIGN.md section 4, 'Round 6' (c)): the HBM side is "
+                                    "about 1.5 x the algorithmic 5.1 GB, not 4 x")
         roof["note"] = ("achieved = f16 MFMA FLOPs the dominant kernel issues per launch (algorithmic direct-conv FLOPs 2*27*Cin*Cout*V, unpadded, x "
                         "executed_per_algorithmic: / 2 for Winograd F(4,3) [/ 1.5 for F(2,3)] x 3 split products x 14/13.5 tap pairing) / average launch "
                         "time from HIP events on the launch stream; peak = 2500 TF dense f16 MFMA; frac is a hardware fraction (<= 1) and should equal "
