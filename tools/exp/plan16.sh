@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6: slab-DMA placements of the tap-split F(2,3) kernels conv_wino16_kernel<64> / <32> (dev builds: make -C mica_amd/csrc exp_plan16)
+# Round 6: slab-DMA placements of the tap-split F(2,3) kernels conv_wino16_kernel<64> / <32> (dev builds: make -C mica_amd/csrc exp_plan16 PLAN16_VARIANTS="1 2 3 4"; TWOAHEAD is always built)
 # against the shipped placement, single layers, one 64^3 tile, kernel-trace averages.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
