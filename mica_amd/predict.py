@@ -29,8 +29,9 @@ class CryoEMPredictor:
         (BASELINE.json configs[2]): this process is rank 0, ranks 1 .. N-1 are persistent child processes that mica_amd/multi.py starts
         (once, kept for the next map, gone with the process); the volumes GridCreator left on this GPU are broadcast to them over
         RCCL, every rank runs its share of the tile batches and the cropped records come back to this rank, which stitches.  The
-        volumes are bit-identical to gpus=1.  Applies to the resident route (the tiler ran in this process); the tile-file route
-        reads its files in one process and stays on one GPU;
+        volumes are bit-identical to gpus=1.  When the tiler ran elsewhere, the volumes are rebuilt from its tile files first (a
+        complete set: the tiler is a pure copy) and sharded the same way; an incomplete set is read tile by tile on one GPU, as the
+        reference does;
         `batch_size` - tiles per forward call (results do not depend on it with per-tile gating);
         `reference_batching` - reproduce the reference's batching exactly (utils/predict.py:176-215, 278-286): batch 1
         up to `batch_threshold` tiles (= per-tile AF3 gating), above it batches of `optimal_batch_size` (at most 8) tiles in
@@ -263,33 +264,101 @@ class CryoEMPredictor:
         tiles, per-tile AF3 gating (= the reference at batch size 1 and = the file route of this class), the four volumes
         downloaded slab by slab while later tiles compute.  A directory without encodings, or with fewer than the 24 channels,
         means zeros for every tile (dataset/dataset.py:218-219) = the exp_downsizing branch."""
+        m, a = self.resident
+        for ent in self.resident:            # the tile-file writers held back for the tiler's and the weight load's sake: go
+            if ent is not None and ent.writer is not None:
+                ent.writer.release()
+        af = a.volume if a is not None and len(a.channels) == 24 else None
+        return self._predict_volumes(m.volume, af, m.grid_size, m.padding)
+
+    def _predict_volumes(self, vol, af, grid, pad):
+        """vol f32 [N0,N1,N2] / af u8 or f32 [24,N0,N1,N2] (or None) on this predictor's GPU -> the dict of four host volumes, on one GPU
+        or - `gpus` > 1 - sharded over the ranks of mica_amd/multi.py; None (+ log) on failure, like run_inference."""
         t0 = time.time()
         try:
             from .pipeline import VolumePredictor
-            m, a = self.resident
-            for ent in self.resident:            # the tile-file writers held back for the tiler's and the weight load's sake: go
-                if ent is not None and ent.writer is not None:
-                    ent.writer.release()
-            af = a.volume if a is not None and len(a.channels) == 24 else None
             if self.gpus > 1:
                 from . import multi
                 self.rank_pool = pool = multi.get_pool(self.gpus, tile=self.engine.tile_size, batch=self.engine.max_batch, backend=self.rank_backend,
                                                        devices=self.rank_devices, conv_variant=None)
                 runner = multi.EngineRunner(None, self.engine.tile_size, self.engine.max_batch, engine=self.engine, loaded_model=self.model_path)
                 try:
-                    vols = pool.predict(runner, self.model_path, m.volume, af, m.grid_size, m.padding, gather_to_root=self.gather_to_root, to_host=True)
+                    vols = pool.predict(runner, self.model_path, vol, af, grid, pad, gather_to_root=self.gather_to_root, to_host=True)
                 finally:
                     if runner.engine is not self.engine:      # the runner had to build a fresh context (the checkpoint changed under it)
                         self.engine.close()
                         self.engine = runner.engine
             else:
-                vols = VolumePredictor(self.engine, m.grid_size, m.padding, self.engine.max_batch).predict_volume(m.volume, af, to_host=True)
+                vols = VolumePredictor(self.engine, grid, pad, self.engine.max_batch).predict_volume(vol, af, to_host=True)
             self.timing_stats['inference'] = time.time() - t0
             return vols
         except Exception as e:
             self.logger.error(f"Inference failed: {e}")
             self.timing_stats['inference'] = time.time() - t0
             return None
+
+    def _volumes_from_tile_files(self):
+        """The map (and the 24 encoding channels) rebuilt from a COMPLETE set of tile files - the tiler is a pure copy and the tiles'
+        central regions cover the volume exactly once (utils/create_grids.py:143-157, utils/predict.py:494-501) - so that `gpus` > 1
+        also serves a predictor whose tiler ran elsewhere: -> (vol f32 device, af u8 / f32 device or None, grid, pad), or None when the
+        set is not one this shortcut reproduces exactly (a tile of the table missing, an encoding tile missing or unreadable - the
+        reference then feeds zeros for that tile's 24 channels, dataset/dataset.py:218-219 -, windows of another size than the engine's):
+        the caller falls back to reading tile by tile on one GPU."""
+        from concurrent.futures import ThreadPoolExecutor
+        from ._cabi import tile_table
+        from .dataset import AF3_TYPES, read_npz_grid
+        files = glob.glob(f"{self.grids_path}/normalized_map_grids/*.npz")
+        if not files:
+            return None
+        metas = []
+        for f in files:
+            d = np.load(f)
+            metas.append((int(d['i']), int(d['j']), int(d['k']), int(d['di']), int(d['dj']), int(d['dk']),
+                          tuple(int(x) for x in np.asarray(d['orig_shape']).flatten()), int(d['grid_size']) if 'grid_size' in d else 48,
+                          int(d['padding']) if 'padding' in d else 8))
+        shape, grid, pad = metas[0][6], metas[0][7], metas[0][8]
+        table = {tuple(int(v) for v in row[:3]) for row in tile_table(*shape, grid)}
+        if any(m[6:] != (shape, grid, pad) for m in metas) or {m[:3] for m in metas} != table or len(metas) != len(table):
+            return None
+        afdir = os.path.join(self.grids_path, "AF3_encoding_grids")
+        with_af = os.path.isdir(afdir)
+        vol = np.zeros(shape, np.float32)
+        af = np.zeros((24, *shape), np.uint8) if with_af else None
+        state = {"af": af, "ok": True}
+
+        def place(q):
+            i, j, k, di, dj, dk = metas[q][:6]
+            core = (slice(pad, pad + di), slice(pad, pad + dj), slice(pad, pad + dk))
+            dst = (slice(i, i + di), slice(j, j + dj), slice(k, k + dk))
+            vol[dst] = read_npz_grid(files[q])[core]
+            if with_af:
+                tiles = []
+                for t in AF3_TYPES:
+                    p = files[q].replace('normalized_map_grids', f"AF3_encoding_grids/{t}_grids").replace('normalized_map', f"{t}")
+                    tiles.append(read_npz_grid(p)[core])
+                return q, dst, tiles
+            return q, dst, None
+        try:
+            with ThreadPoolExecutor(max_workers=self.loader_threads) as pool:
+                for q, dst, tiles in pool.map(place, range(len(files))):
+                    if tiles is None:
+                        continue
+                    for c, g in enumerate(tiles):
+                        a = state["af"]
+                        if a.dtype == np.uint8:
+                            u = g.astype(np.uint8)
+                            if not np.array_equal(u, g):                 # not a binary encoding: keep the values as they are
+                                state["af"] = a = a.astype(np.float32)
+                                a[(c, *dst)] = g
+                            else:
+                                a[(c, *dst)] = u
+                        else:
+                            a[(c, *dst)] = g
+        except Exception as e:
+            self.logger.warning(f"tile files under {self.grids_path} are not a complete set ({e}): reading tile by tile on one GPU")
+            return None
+        dev = torch.device(self.device if ":" in str(self.device) else "cuda:0")
+        return torch.from_numpy(vol).to(dev), None if state["af"] is None else torch.from_numpy(state["af"]).to(dev), grid, pad
 
     @staticmethod
     def close_ranks():
@@ -308,12 +377,22 @@ class CryoEMPredictor:
                 from . import multi
                 multi.get_pool(self.gpus, tile=self.resident[0].grid_size + 2 * self.resident[0].padding, batch=self.batch_size,
                                backend=self.rank_backend, devices=self.rank_devices, conv_variant=None).spawn()
-            elif self.gpus > 1:
-                self.logger.warning("gpus > 1 applies to volumes the tiler of this process left on the GPU; the tile-file route runs on one GPU")
-            if not self.load_model():
+            from_files = None
+            if self.gpus > 1 and self.resident is None and not self.reference_batching:
+                # the tiler ran elsewhere: rebuild the volumes from its (complete) tile files and shard those
+                from_files = self._volumes_from_tile_files()
+                if from_files is None:
+                    self.logger.warning("gpus > 1: the tile files are not a complete set this route reproduces exactly; reading tile by tile on one GPU")
+                else:
+                    from . import multi
+                    multi.get_pool(self.gpus, tile=from_files[2] + 2 * from_files[3], batch=self.batch_size, backend=self.rank_backend,
+                                   devices=self.rank_devices, conv_variant=None).spawn()
+            if not self.load_model(tile_size=None if from_files is None else from_files[2] + 2 * from_files[3]):
                 return False, {}
             if self.resident is not None:
                 vols = self.run_inference_resident()
+            elif from_files is not None:
+                vols = self._predict_volumes(*from_files)
             else:
                 ok, dataset = self.prepare_data()
                 if not ok:

@@ -250,6 +250,33 @@ def test_config2_through_the_product_entry_two_ranks_on_one_gpu(tmp_path, weight
     assert ok and ok2 and p3.rank_pool is p2.rank_pool and p3.rank_pool.procs[0] is worker and worker.poll() is None and p3.rank_pool.maps == 2
     for k in ref2:
         assert np.array_equal(ref2[k], two2[k]), k
+    # the tiler ran elsewhere (only its FILES exist): the volumes are rebuilt from the complete set of tile files and sharded the same
+    # way; with one encoding tile file missing the set is not one the shortcut reproduces exactly (the reference feeds zeros for that
+    # tile's 24 channels): one GPU, tile by tile, and the same volumes as gpus=1 on that directory
+    gsync = str(tmp_path / "m2" / "grids_files")
+    gcs = GridCreator(quiet=True, write_files="sync")
+    assert gcs.create_normalized_map_grids(str(tmp_path / "m2" / "resampled_normalized_map.mrc"), os.path.join(gsync, "normalized_map_grids"))["success"]
+    assert gcs.create_AF3_encodings_grids(str(tmp_path / "m2" / "AF3_encodings"), os.path.join(gsync, "AF3_encoding_grids"))["success"]
+
+    def from_files(gpus):
+        pred = CryoEMPredictor(model_path=ck, grids_path=gsync + "/", output_path=str(tmp_path / "out"), save_output=False, device="cuda",
+                               quiet=True, batch_size=2, gpus=gpus)
+        pred.rank_backend, pred.rank_devices = "gloo", [0, 0]
+        pred.use_resident_volumes = False                      # what a predictor in another process sees: the files, nothing resident
+        ok, vols = pred.run_prediction()
+        assert ok and pred.resident is None
+        return vols, pred
+    files2, pf = from_files(2)
+    assert pf.rank_pool is p2.rank_pool and pf.rank_pool.maps == 3 and pf.rank_pool.procs[0] is worker
+    for k in ref2:
+        assert np.array_equal(ref2[k], files2[k]), k
+    os.remove(glob.glob(os.path.join(gsync, "AF3_encoding_grids", "CA_grids", "*.npz"))[0])
+    one_gpu, _ = from_files(1)
+    fallback, pb = from_files(2)
+    assert pb.rank_pool is None or pb.rank_pool.maps == 3      # not sharded: read tile by tile, like the reference
+    for k in one_gpu:
+        assert np.array_equal(one_gpu[k], fallback[k]), k
+    assert not np.array_equal(one_gpu["backbone_probability"], ref2["backbone_probability"])     # that tile lost its encodings
     # failure: the checkpoint vanishes between the strategy step and the workers' load -> (False, {}), pool closed, worker gone
     bad = str(tmp_path / "gone.pth")
     _save_ckpt(bad, weights)
@@ -258,8 +285,8 @@ def test_config2_through_the_product_entry_two_ranks_on_one_gpu(tmp_path, weight
     pred.rank_backend, pred.rank_devices, pred.keep_resident_volumes = "gloo", [0, 0], True
     real_load = pred.load_model
 
-    def load_then_remove():
-        r = real_load()
+    def load_then_remove(**kw):
+        r = real_load(**kw)
         os.remove(bad)
         return r
     pred.load_model = load_then_remove
