@@ -393,10 +393,16 @@ class RankPool:
         finally:
             self._kill()
             if self.joined and dist.is_initialized():
-                try:
-                    dist.destroy_process_group()
-                except Exception:
-                    pass
+                # leaving the group can block when a collective of this rank is still pending on peers that are gone (RCCL): it runs
+                # on a helper thread and the caller gets its exception / its volumes after at most 15 s either way
+                def leave():
+                    try:
+                        dist.destroy_process_group()
+                    except Exception:
+                        pass
+                th = threading.Thread(target=leave, name="mica-rank-leave", daemon=True)
+                th.start()
+                th.join(15.0)
             self.joined = False
             self.store = None
             with _LOCK:
