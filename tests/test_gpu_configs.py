@@ -319,8 +319,8 @@ def test_config2_through_the_product_entry_two_ranks_on_one_gpu(tmp_path, weight
 
     def solver_flow(tag):
         import time
-        t0 = time.time()
         dp = sm.DataPreprocessor(map_path=str(inp / "emd_9999.mrc"), AF3_results=str(inp / "AF3_results"), quiet=True)
+        t0 = time.time()                                   # the constructor has returned: the workers (if any) are already started
         dp.resample_and_normalize_map()
         grids = str(tmp_path / "solver" / tag)
         gc = sm.GridCreator(quiet=True)
@@ -336,7 +336,7 @@ def test_config2_through_the_product_entry_two_ranks_on_one_gpu(tmp_path, weight
     try:
         two, pred, t0 = solver_flow("two")
         assert pred.gpus == 2 and pred.rank_pool is not None and pred.rank_pool.maps == 1 and pred.rank_pool.last_status[0]["stats"]["world"] == 2
-        assert pred.rank_pool.t_spawn - t0 < 0.5                       # spawned by DataPreprocessor's constructor, not by the predictor
+        assert pred.rank_pool.t_spawn <= t0                            # spawned by DataPreprocessor's constructor, not by the predictor
         for k in one:
             assert np.array_equal(one[k], two[k]), k
     finally:
