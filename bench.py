@@ -499,10 +499,24 @@ def main():
                         "and the 3-product split: 833 TF ceiling) is in algorithmic_tflops; traffic = PMC HBM bytes per launch at batch 8 (rocprofv3 "
                         "--pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections), null when the committed profile was taken on other library sources")
         dach = dbytes / (dms * 1e-3) / 1e9
+        # what a plain streaming kernel (y = 2 x, one read + one write per element, 2.7 GB) reaches on THIS box: the practical ceiling the
+        # depthwise kernel's traffic shape could approach (MI355X_MICROARCH.md: ~6.3 TB/s achievable of the 8 TB/s peak) - context, not product
+        sx = torch.empty(336 * 1024 * 1024, dtype=torch.float32, device=dev).normal_()
+        sy = torch.empty_like(sx)
+        torch.mul(sx, 2.0, out=sy)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            torch.mul(sx, 2.0, out=sy)
+        e1.record()
+        torch.cuda.synchronize()
+        plain = 5 * 2 * sx.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del sx, sy
         hbm = {"bound": "hbm", "kernel": "depthwise_kernel (Conv3d groups=C, 3x3x3, IN+ReLU+SE gate fused on load, IN stats fused)",
                "achieved": dach, "peak": 8000.0, "unit": "GB/s", "frac": dach / 8000.0,
                "traffic": traffic.get("depthwise_kernel", {}).get("hbm_bytes"), "launches_per_batch": dl,
                "avg_launch_ms": dms / max(dl, 1), "algorithmic_bytes_per_launch": dbytes / max(dl, 1),
+               "plain_stream_gbs_on_this_box": plain, "frac_of_plain_stream": dach / plain,
                "note": "BASELINE metric's 'HBM GB/s on conv3d': algorithmic 8 B per voxel and channel / HIP-event time"}
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
